@@ -1,0 +1,188 @@
+/*
+ * hipac.h -- C ABI of libhipac_hip.so, the MI355X (gfx950) implementation of
+ * HiPAC's patch-inference hot path.
+ *
+ * The reference (anacarsi/ss25_Hierarchical_Multiscale_Image_Classification)
+ * exposes no plugin / FFI interface for this path: it is reached through plain
+ * Python call sites.  Each entry point below names the reference code whose
+ * arithmetic it replaces (file:line relative to the reference root); the
+ * Python-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary
+ *   - every `const void* / void*` data pointer is DEVICE memory unless the
+ *     parameter comment says "host"
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); no entry point synchronises the device
+ *     except hipac_resnet18_pack (one-time upload) and hipac_weights_free
+ *   - the caller owns every buffer including the workspace; the library owns
+ *     only the packed-weights handle
+ *   - return value: 0 on success, otherwise a hipError_t value or one of the
+ *     HIPAC_E* codes; nothing throws across the ABI; hipac_last_error() gives
+ *     a thread-local message for the last failure
+ *   - re-entrant: no global mutable state; a weights handle may be used from
+ *     several streams concurrently (read-only)
+ */
+#ifndef HIPAC_H_
+#define HIPAC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPAC_ABI_VERSION 1
+
+/* error codes (positive small values are hipError_t) */
+#define HIPAC_EINVAL (-1)     /* bad argument (shape, enum, null pointer, alignment) */
+#define HIPAC_EWORKSPACE (-2) /* workspace too small */
+#define HIPAC_EUNSUPPORTED (-3)
+
+/* arithmetic type of the network's MFMA operands (accumulation is always fp32) */
+#define HIPAC_PREC_BF16 0
+#define HIPAC_PREC_FP16 1
+
+/* input layouts accepted by hipac_resnet18_forward */
+#define HIPAC_IN_NCHW_F32 0   /* float32[B,3,224,224], the reference's layout (src/main.py:870) */
+#define HIPAC_IN_NHWC4_PAD 1  /* native: T[B,230,232,4] (T = bf16|fp16 per precision), the
+                                 224x224 image at rows 3..226, cols 3..226, channel 3 and the
+                                 border all zero.  Written directly by hipac_tile_preprocess. */
+
+/* output formats of hipac_tile_preprocess */
+#define HIPAC_OUT_NCHW_F32 0     /* float32[n,3,224,224] == Resize->ToTensor->Normalize */
+#define HIPAC_OUT_NHWC4_PAD_BF16 1
+#define HIPAC_OUT_NHWC4_PAD_FP16 2
+#define HIPAC_OUT_U8_HWC 3       /* uint8[n,224,224,3]: the resized pixels before ToTensor */
+
+#define HIPAC_PATCH 224
+#define HIPAC_PAD_H 230
+#define HIPAC_PAD_W 232
+
+int hipac_abi_version(void);
+const char* hipac_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * ResNet18 weights
+ * ------------------------------------------------------------------------- */
+
+/* One conv + its eval-mode BatchNorm, HOST float32 pointers in PyTorch layout. */
+typedef struct hipac_convbn {
+  const float* conv_w;   /* [Cout, Cin, kh, kw] */
+  const float* bn_gamma; /* [Cout] (bn.weight)       */
+  const float* bn_beta;  /* [Cout] (bn.bias)         */
+  const float* bn_mean;  /* [Cout] (bn.running_mean) */
+  const float* bn_var;   /* [Cout] (bn.running_var)  */
+} hipac_convbn_t;
+
+/* The tensors of torchvision.models.resnet18 as the reference instantiates it
+ * (src/models/resnet.py:25, :45, :63-65; src/models/simclr.py:17).
+ * block[2*s + b][c] = layer{s+1}.{b}.conv{c+1}/bn{c+1};  down[s-1] =
+ * layer{s+1}.0.downsample.{0,1} for s = 1..3.  fc_w/fc_b may be NULL
+ * (fc = Identity, resnet.py:46) and then num_classes must be 0. */
+typedef struct hipac_resnet18_params {
+  hipac_convbn_t stem;        /* conv1 [64,3,7,7] + bn1 */
+  hipac_convbn_t block[8][2];
+  hipac_convbn_t down[3];
+  const float* fc_w;          /* host float32 [num_classes, 512] or NULL */
+  const float* fc_b;          /* host float32 [num_classes] or NULL */
+  int32_t num_classes;        /* 0..16 */
+  float bn_eps;               /* 1e-5 */
+} hipac_resnet18_params_t;
+
+typedef struct hipac_weights hipac_weights_t;
+
+/* Fold BN into the convs (w' = w*gamma/sqrt(var+eps), b' = beta - mean*gamma/
+ * sqrt(var+eps)), round to `precision`, repack to the MFMA-friendly
+ * [Cout][kh][kw][Cin] layout and upload.  Replaces the per-forward
+ * conv->batch_norm pairs torchvision executes (call sites resnet.py:38-40,
+ * :54-55, :69-77).  Synchronous; call once per state_dict. */
+int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hipac_weights_t** out);
+void hipac_weights_free(hipac_weights_t* w);
+int hipac_weights_precision(const hipac_weights_t* w);
+int hipac_weights_num_classes(const hipac_weights_t* w);
+
+/* Bytes of caller-provided scratch needed for a forward of `batch` patches. */
+size_t hipac_resnet18_workspace_bytes(int batch, int precision);
+
+/* Batched ResNet18 eval forward.  Replaces
+ *   ResNet18FeatureExtractor.forward   src/models/resnet.py:38-40  -> feats
+ *   UnifiedResNet.forward              src/models/resnet.py:54-55  -> feats | logits
+ *   ResNet18Classifier.forward         src/models/resnet.py:69-77  -> logits
+ * as called from src/main.py:870 (extract_features), :920, :505/:519 (train /
+ * val scoring) and :1009.
+ *   x       : `batch` patches in `in_layout`
+ *   feats   : float32[batch,512] or NULL
+ *   logits  : float32[batch,num_classes] or NULL (requires fc in the handle)
+ *   labels  : int64[batch] argmax(logits, dim=1) (src/main.py:510) or NULL
+ */
+int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, int in_layout,
+                           float* feats, float* logits, int64_t* labels,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug / test tap: copy one intermediate activation of the LAST forward run
+ * with this workspace to `dst` as float32 NCHW.  `tap`: 0 stem(after relu),
+ * 1 maxpool, 2..9 output of block 0..7.  Used only by the layer-wise parity
+ * tests. */
+int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap,
+                       float* dst, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Tile / crop / whiteness / resize / normalise
+ * ------------------------------------------------------------------------- */
+
+/* Pillow's resampling tables for one window size P -> 224 (HOST int32).
+ * bounds[224*2] = (first source index, tap count); kk[224*ksize] = 22-bit
+ * fixed-point weights.  Computed in IEEE double exactly like
+ * Pillow's precompute_coeffs / normalize_coeffs_8bpc (libImaging/Resample.c),
+ * the code torchvision.transforms.Resize reaches for a PIL image
+ * (reference call site src/main.py:814).  Returns ksize, or <0 on error.
+ * `bounds`/`kk` may be NULL to query ksize only. */
+int hipac_resample_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int kk_stride);
+/* level base pointer and pitch must be 16-byte aligned when P > 224. */
+
+/* Per-window crop + white border pad + whiteness sum + antialiased bilinear
+ * resize to 224x224 + ToTensor/Normalize, for `n` windows of one pyramid
+ * level that is resident in HBM.  Replaces, per window,
+ *   read_region(...).convert("RGB")          src/main.py:693-697
+ *   paste on a white PxP canvas              src/main.py:699-703
+ *   np.mean(patch) > 240 -> drop             src/main.py:718-720
+ *   Resize((224,224)) / ToTensor / Normalize src/main.py:812-818 (Pillow + torch)
+ *
+ *   level     : uint8 image, `chans` (3 = RGB, 4 = RGBA, alpha ignored) bytes
+ *               per pixel, row pitch `pitch` bytes, W x H pixels
+ *   xy        : int32[n,2] window origins in level pixels (0 <= x < W, 0 <= y < H;
+ *               for P > 224, x must be a multiple of 16 -- the reference's grid
+ *               strides by 224, src/main.py:682)
+ *   P         : window size 224*s, s in 1..8 (224, 448, 896, 1792 in the reference)
+ *   coeff_bounds, coeff_kk, ksize : DEVICE copies of hipac_resample_coeffs(P, 224,
+ *               ..., kk_stride = ksize); may be NULL when P == 224 (identity)
+ *   lut       : float32[3,256] = (v/255 - mean_c)/std_c evaluated in fp32
+ *   out       : per `out_format`
+ *   sums      : uint32[n] sum of the padded PxPx3 window (NULL to skip)
+ *   keep      : uint8[n] 1 iff sum <= 240*3*P*P, i.e. not (mean > 240) (NULL to skip)
+ */
+int hipac_tile_preprocess(const uint8_t* level, int W, int H, int64_t pitch, int chans,
+                          const int32_t* xy, int n, int P,
+                          const int32_t* coeff_bounds, const int32_t* coeff_kk, int ksize,
+                          const float* lut,
+                          void* out, int out_format, uint32_t* sums, uint8_t* keep,
+                          void* stream);
+
+/* tumour / normal label per window: 1 iff any mask pixel > 0 inside
+ * [x,x+P) x [y,y+P) (pixels outside the mask count as 0).
+ * Replaces mask.crop(...) / np.any(... > 0), src/main.py:707-712. */
+int hipac_window_labels(const uint8_t* mask, int W, int H, int64_t pitch,
+                        const int32_t* xy, int n, int P, uint8_t* labels, void* stream);
+
+/* uint8[n,224,224,3] patches (already 224x224, e.g. decoded level-3 PNGs) ->
+ * network input in `out_format` (ToTensor + Normalize only; Resize is the
+ * identity at 224, src/main.py:814). */
+int hipac_patches_normalize(const uint8_t* patches, int n, const float* lut,
+                            void* out, int out_format, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPAC_H_ */

@@ -1,0 +1,78 @@
+"""Build libhipac_hip.so (gfx950) in-tree with hipcc.
+
+Cross-compiles without a GPU.  The .so stays inside the package directory so it
+travels with the tree (it is git-ignored, not gpurun-ignored).
+
+    python -m ss25_hierarchical_multiscale_image_classification_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "build"
+LIB = PKG / "libhipac_hip.so"
+SOURCES = ["hipac_capi.hip", "preprocess.hip", "conv_bf16.hip", "conv_f16.hip"]
+HEADERS = ["common.h", "conv_igemm.h", "../../include/hipac.h"]
+ARCH = "gfx950"
+# -ffp-contract=off: the host-side Pillow coefficient restatement must round every
+# double operation separately (no fused multiply-add), see preprocess.hip.
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [CSRC / h for h in HEADERS] + [Path(__file__)]
+    jobs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = OBJ / (Path(src).stem + ".o")
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc, *FLAGS, "-c", str(s), "-o", str(o)]
+        if verbose:
+            print("[hipac build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s.name}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [OBJ / (Path(src).stem + ".o") for src in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print("[hipac build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

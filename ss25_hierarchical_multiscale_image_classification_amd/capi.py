@@ -1,0 +1,379 @@
+"""ctypes binding of libhipac_hip.so (the C ABI in include/hipac.h).
+
+PyTorch appears here only as the owner of device memory and streams: tensors are
+handed to the library as raw pointers, and every launch goes on torch's current
+HIP stream.  There is no CPU fallback: if the library is missing or a call
+fails, a ``HipacError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libhipac_hip.so"
+
+PREC_BF16, PREC_FP16 = 0, 1
+IN_NCHW_F32, IN_NHWC4_PAD = 0, 1
+OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
+PATCH, PAD_H, PAD_W = 224, 230, 232
+
+PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16}
+TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
+
+
+class HipacError(RuntimeError):
+    pass
+
+
+class ConvBN(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv_w", "bn_gamma", "bn_beta", "bn_mean", "bn_var")]
+
+
+class ResNet18Params(C.Structure):
+    _fields_ = [
+        ("stem", ConvBN),
+        ("block", (ConvBN * 2) * 8),
+        ("down", ConvBN * 3),
+        ("fc_w", C.c_void_p),
+        ("fc_b", C.c_void_p),
+        ("num_classes", C.c_int32),
+        ("bn_eps", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/hipac.h declares.
+SYMBOLS = {
+    "hipac_abi_version": (C.c_int, []),
+    "hipac_last_error": (C.c_char_p, []),
+    "hipac_resnet18_pack": (C.c_int, [C.POINTER(ResNet18Params), C.c_int, C.POINTER(C.c_void_p)]),
+    "hipac_weights_free": (None, [C.c_void_p]),
+    "hipac_weights_precision": (C.c_int, [C.c_void_p]),
+    "hipac_weights_num_classes": (C.c_int, [C.c_void_p]),
+    "hipac_resnet18_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hipac_resnet18_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "hipac_resnet18_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hipac_resample_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "hipac_tile_preprocess": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+         C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "hipac_window_labels": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "hipac_patches_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(path: Optional[os.PathLike] = None):
+    """dlopen the library and bind every symbol.  Raises HipacError if absent."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = Path(path) if path else LIB_PATH
+        if not p.exists():
+            raise HipacError(
+                f"{p} not found: build it with `python -m {__package__}.build` "
+                "(there is no CPU fallback for the HIP path)"
+            )
+        lib = C.CDLL(str(p))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.hipac_abi_version() != 1:
+            raise HipacError(f"ABI version mismatch: {lib.hipac_abi_version()}")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().hipac_last_error().decode(errors="replace")
+        raise HipacError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipacError("HIP path called with a CPU tensor: there is no CPU fallback (move inputs to cuda)")
+        if t is not None and not t.is_contiguous():
+            raise HipacError("HIP path needs contiguous tensors")
+
+
+# ----------------------------------------------------------------------------
+# resampling tables / LUT
+# ----------------------------------------------------------------------------
+
+
+def resample_coeffs(in_size: int, out_size: int = PATCH) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Host tables (bounds int32[out,2], kk int32[out,ksize], ksize) from the
+    library's C++ restatement of Pillow's precompute_coeffs."""
+    lib = load_library()
+    ksize = lib.hipac_resample_coeffs(in_size, out_size, None, None, 0)
+    if ksize <= 0:
+        _check(ksize, "hipac_resample_coeffs")
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    rc = lib.hipac_resample_coeffs(in_size, out_size, bounds.ctypes.data, kk.ctypes.data, ksize)
+    if rc != ksize:
+        _check(rc if rc < 0 else -1, "hipac_resample_coeffs")
+    return bounds, kk, ksize
+
+
+def normalize_lut() -> np.ndarray:
+    """float32[3,256] = (v/255 - mean_c)/std_c in fp32, torchvision's op order
+    (ToTensor .div(255), Normalize sub/div), reference src/main.py:815-816."""
+    v = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32)
+    return ((v[None, :] - mean[:, None]) / std[:, None]).contiguous().numpy()
+
+
+_dev_tables: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, int]] = {}
+_dev_lut: Dict[int, torch.Tensor] = {}
+
+
+def device_tables(P: int, device: torch.device):
+    key = (P, device.index or 0)
+    if key not in _dev_tables:
+        b, k, ksize = resample_coeffs(P, PATCH)
+        _dev_tables[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), ksize)
+    return _dev_tables[key]
+
+
+def device_lut(device: torch.device) -> torch.Tensor:
+    key = device.index or 0
+    if key not in _dev_lut:
+        _dev_lut[key] = torch.from_numpy(normalize_lut()).to(device)
+    return _dev_lut[key]
+
+
+# ----------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------
+
+_STAGE_NAMES = ("layer1", "layer2", "layer3", "layer4")
+
+
+class PackedResNet18:
+    """Owner of a hipac_weights_t handle (BN-folded, repacked, on device)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], precision: str = "bf16", bn_eps: float = 1e-5):
+        """``sd``: bare torchvision-named tensors (conv1.weight, bn1.*, layerK.B.*,
+        optional fc.*).  Use ``weights.canonical_state_dict`` to get there from
+        the reference's key layouts."""
+        if precision not in PRECISIONS:
+            raise HipacError(f"precision must be one of {sorted(PRECISIONS)}")
+        lib = load_library()
+        keep = []
+
+        def host(name):
+            if name not in sd:
+                raise HipacError(f"state dict lacks '{name}'")
+            a = np.ascontiguousarray(sd[name].detach().to("cpu", torch.float32).numpy())
+            keep.append(a)
+            return a.ctypes.data
+
+        def convbn(conv, bn):
+            return ConvBN(host(conv + ".weight"), host(bn + ".weight"), host(bn + ".bias"),
+                          host(bn + ".running_mean"), host(bn + ".running_var"))
+
+        p = ResNet18Params()
+        p.stem = convbn("conv1", "bn1")
+        for s, name in enumerate(_STAGE_NAMES):
+            for b in (0, 1):
+                for c in (0, 1):
+                    p.block[2 * s + b][c] = convbn(f"{name}.{b}.conv{c + 1}", f"{name}.{b}.bn{c + 1}")
+            if s > 0:
+                p.down[s - 1] = convbn(f"{name}.0.downsample.0", f"{name}.0.downsample.1")
+        if "fc.weight" in sd:
+            p.num_classes = int(sd["fc.weight"].shape[0])
+            p.fc_w = host("fc.weight")
+            p.fc_b = host("fc.bias")
+        else:
+            p.num_classes = 0
+            p.fc_w = None
+            p.fc_b = None
+        p.bn_eps = bn_eps
+        handle = C.c_void_p()
+        _check(lib.hipac_resnet18_pack(C.byref(p), PRECISIONS[precision], C.byref(handle)), "hipac_resnet18_pack")
+        self._lib = lib
+        self.handle = handle
+        self.precision = precision
+        self.num_classes = p.num_classes
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and self._lib is not None:
+            self._lib.hipac_weights_free(h)
+            self.handle = None
+
+    def workspace(self, batch: int, device: torch.device) -> torch.Tensor:
+        need = self._lib.hipac_resnet18_workspace_bytes(batch, PRECISIONS[self.precision])
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        self._ws_batch = batch
+        return self._ws
+
+    def forward(
+        self,
+        x: torch.Tensor,
+        want_feats: bool = True,
+        want_logits: bool = False,
+        want_labels: bool = False,
+        native_layout: bool = False,
+    ):
+        """x: float32[B,3,224,224] on cuda, or (native_layout) T[B,230,232,4].
+        Returns (feats|None, logits|None, labels|None), all on x's device."""
+        _require_gpu(x)
+        if native_layout:
+            if tuple(x.shape[1:]) != (PAD_H, PAD_W, 4) or x.dtype != TORCH_DTYPE[PRECISIONS[self.precision]]:
+                raise HipacError(f"native input must be {self.precision}[B,{PAD_H},{PAD_W},4], got {x.dtype}{tuple(x.shape)}")
+        else:
+            if tuple(x.shape[1:]) != (3, PATCH, PATCH) or x.dtype != torch.float32:
+                raise HipacError(f"input must be float32[B,3,224,224], got {x.dtype}{tuple(x.shape)}")
+        B = x.shape[0]
+        dev = x.device
+        if (want_logits or want_labels) and self.num_classes == 0:
+            raise HipacError("logits requested but the model has fc = Identity")
+        feats = torch.empty((B, 512), dtype=torch.float32, device=dev) if want_feats else None
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=dev) if want_logits else None
+        labels = torch.empty((B,), dtype=torch.int64, device=dev) if want_labels else None
+        if B == 0:
+            return feats, logits, labels
+        ws = self.workspace(B, dev)
+        with torch.cuda.device(dev):
+            rc = self._lib.hipac_resnet18_forward(
+                self.handle, x.data_ptr(), B, IN_NHWC4_PAD if native_layout else IN_NCHW_F32,
+                _ptr(feats), _ptr(logits), _ptr(labels), ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "hipac_resnet18_forward")
+        return feats, logits, labels
+
+    def tap(self, batch: int, tap: int) -> torch.Tensor:
+        """Intermediate activation of the last forward (float32 NCHW); tests only."""
+        shapes = [(64, 112), (64, 56), (64, 56), (64, 56), (128, 28), (128, 28), (256, 14), (256, 14), (512, 7), (512, 7)]
+        c, h = shapes[tap]
+        dst = torch.empty((batch, c, h, h), dtype=torch.float32, device=self._ws.device)
+        with torch.cuda.device(dst.device):
+            _check(self._lib.hipac_resnet18_tap(self.handle, self._ws.data_ptr(), batch, tap, dst.data_ptr(), _stream()),
+                   "hipac_resnet18_tap")
+        return dst
+
+
+# ----------------------------------------------------------------------------
+# tile preprocess
+# ----------------------------------------------------------------------------
+
+_OUT_FMT = {"nchw_f32": OUT_NCHW_F32, "bf16": OUT_NHWC4_PAD_BF16, "fp16": OUT_NHWC4_PAD_FP16, "u8": OUT_U8_HWC}
+
+
+def _alloc_out(n: int, fmt: str, device) -> torch.Tensor:
+    if fmt == "nchw_f32":
+        return torch.empty((n, 3, PATCH, PATCH), dtype=torch.float32, device=device)
+    if fmt == "u8":
+        return torch.empty((n, PATCH, PATCH, 3), dtype=torch.uint8, device=device)
+    return torch.empty((n, PAD_H, PAD_W, 4), dtype=torch.bfloat16 if fmt == "bf16" else torch.float16, device=device)
+
+
+def tile_preprocess(
+    level: torch.Tensor,
+    xy: torch.Tensor,
+    P: int,
+    out_format: str = "nchw_f32",
+    width: Optional[int] = None,
+    want_sums: bool = True,
+    out: Optional[torch.Tensor] = None,
+):
+    """level: uint8[H, Wp, C] on cuda (C = 3|4; Wp >= width is the padded row
+    length, Wp*C a multiple of 16 when P > 224); xy: int32[n,2] on cuda.
+    Returns (out, sums uint32-as-int64|None, keep uint8|None)."""
+    _require_gpu(level, xy)
+    if level.dtype != torch.uint8 or level.dim() != 3 or level.shape[2] not in (3, 4):
+        raise HipacError("level must be uint8[H,W,3|4]")
+    if xy.dtype != torch.int32 or xy.dim() != 2 or xy.shape[1] != 2:
+        raise HipacError("xy must be int32[n,2]")
+    if out_format not in _OUT_FMT:
+        raise HipacError(f"out_format must be one of {sorted(_OUT_FMT)}")
+    H, Wp, ch = level.shape
+    W = Wp if width is None else int(width)
+    n = xy.shape[0]
+    dev = level.device
+    if out is None:
+        out = _alloc_out(n, out_format, dev)
+    sums = torch.empty((n,), dtype=torch.int32, device=dev) if want_sums else None
+    keep = torch.empty((n,), dtype=torch.uint8, device=dev) if want_sums else None
+    if n == 0:
+        return out, sums, keep
+    lib = load_library()
+    if P > PATCH:
+        b, k, ksize = device_tables(P, dev)
+        bp, kp = b.data_ptr(), k.data_ptr()
+    else:
+        bp, kp, ksize = None, None, 0
+    lut = device_lut(dev)
+    with torch.cuda.device(dev):
+        rc = lib.hipac_tile_preprocess(level.data_ptr(), W, H, Wp * ch, ch, xy.data_ptr(), n, P, bp, kp, ksize,
+                                       lut.data_ptr(), out.data_ptr(), _OUT_FMT[out_format], _ptr(sums), _ptr(keep),
+                                       _stream())
+    _check(rc, "hipac_tile_preprocess")
+    return out, sums, keep
+
+
+def window_labels(mask: torch.Tensor, xy: torch.Tensor, P: int) -> torch.Tensor:
+    """mask: uint8[H,W] on cuda; returns uint8[n] (1 = tumour)."""
+    _require_gpu(mask, xy)
+    if mask.dtype != torch.uint8 or mask.dim() != 2:
+        raise HipacError("mask must be uint8[H,W]")
+    n = xy.shape[0]
+    labels = torch.empty((n,), dtype=torch.uint8, device=mask.device)
+    if n == 0:
+        return labels
+    H, W = mask.shape
+    with torch.cuda.device(mask.device):
+        rc = load_library().hipac_window_labels(mask.data_ptr(), W, H, W, xy.data_ptr(), n, P, labels.data_ptr(), _stream())
+    _check(rc, "hipac_window_labels")
+    return labels
+
+
+def patches_normalize(patches: torch.Tensor, out_format: str = "nchw_f32") -> torch.Tensor:
+    """uint8[n,224,224,3] on cuda -> network input (ToTensor + Normalize)."""
+    _require_gpu(patches)
+    if patches.dtype != torch.uint8 or tuple(patches.shape[1:]) != (PATCH, PATCH, 3):
+        raise HipacError("patches must be uint8[n,224,224,3]")
+    n = patches.shape[0]
+    out = _alloc_out(n, out_format, patches.device)
+    if n == 0:
+        return out
+    lut = device_lut(patches.device)
+    with torch.cuda.device(patches.device):
+        rc = load_library().hipac_patches_normalize(patches.data_ptr(), n, lut.data_ptr(), out.data_ptr(),
+                                                    _OUT_FMT[out_format], _stream())
+    _check(rc, "hipac_patches_normalize")
+    return out

@@ -1,0 +1,363 @@
+// C-ABI entry points of libhipac_hip.so: weight packing (BN fold + repack), the
+// ResNet18 forward driver, and the small elementwise kernels around the trunk.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace hipac {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- host-side rounding to the storage type (round-to-nearest-even) ----------------
+static inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline uint16_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;  // host compiler: IEEE RNE conversion
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+static inline uint16_t to_bits(float f, int precision) {
+  return precision == HIPAC_PREC_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+}
+
+Plan make_plan(int batch) {
+  Plan p;
+  // Sub-batch: large enough to fill 256 CUs in layer4 (49 pixels/image), small
+  // enough that one sub-batch's activations stay inside the 256 MiB Infinity Cache.
+  p.bc = batch < 128 ? batch : 128;
+  if (p.bc < 1) p.bc = 1;
+  const size_t b = (size_t)p.bc;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  p.xin = take(b * kPadH * kPadW * 4 * 2);
+  p.stem = take(b * 112 * 112 * 64 * 2);
+  p.pool = take(b * 56 * 56 * 64 * 2);
+  p.tmp = take(b * 56 * 56 * 64 * 2);
+  p.ds = take(b * 28 * 28 * 128 * 2);
+  const int hw[4] = {56, 28, 14, 7};
+  const int ch[4] = {64, 128, 256, 512};
+  for (int s = 0; s < 4; ++s)
+    for (int k = 0; k < 2; ++k) {
+      const size_t esz = (s == 3 && k == 1) ? 4 : 2;
+      p.blk[2 * s + k] = take(b * hw[s] * hw[s] * ch[s] * esz);
+    }
+  p.total = off;
+  return p;
+}
+
+// ---- small kernels ------------------------------------------------------------------
+
+// float32 NCHW [n,3,224,224] -> T NHWC4 zero-padded [n,230,232,4]
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, T* __restrict__ out,
+                                                            int n) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * kPadH * kPadW;
+  if (gid >= total) return;
+  const int px = (int)(gid % kPadW);
+  const long long t = gid / kPadW;
+  const int py = (int)(t % kPadH);
+  const int b = (int)(t / kPadH);
+  const int y = py - 3, xx = px - 3;
+  typename Elem<T>::vec4 v;
+  v[0] = v[1] = v[2] = v[3] = (T)0.f;
+  if ((unsigned)y < (unsigned)kPatch && (unsigned)xx < (unsigned)kPatch) {
+    const size_t plane = (size_t)kPatch * kPatch;
+    const float* src = x + (size_t)b * 3 * plane + (size_t)y * kPatch + xx;
+    v[0] = (T)src[0];
+    v[1] = (T)src[plane];
+    v[2] = (T)src[2 * plane];
+  }
+  *reinterpret_cast<typename Elem<T>::vec4*>(out + (size_t)gid * 4) = v;
+}
+
+int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s) {
+  const long long total = (long long)n * kPadH * kPadW;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (precision == HIPAC_PREC_BF16)
+    hipLaunchKernelGGL((nchw_to_nhwc4_kernel<__bf16>), dim3(grid), dim3(256), 0, s, x, (__bf16*)out, n);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc4_kernel<_Float16>), dim3(grid), dim3(256), 0, s, x, (_Float16*)out, n);
+  return (int)hipGetLastError();
+}
+
+// Global average pool over the 7x7 map of the last block (float32 NHWC
+// [n,49,512]) -> feats[n,512]; optional fc -> logits[n,C]; optional argmax.
+// One 256-thread workgroup per image, two channels per thread.
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ last, const float* __restrict__ fc_w,
+                                                   const float* __restrict__ fc_b, int num_classes,
+                                                   float* __restrict__ feats, float* __restrict__ logits,
+                                                   long long* __restrict__ labels) {
+  __shared__ float red[4][16];
+  __shared__ float lg[16];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* src = last + (size_t)b * 49 * 512 + tid * 2;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 7
+  for (int p = 0; p < 49; ++p) {
+    const float2 v = *reinterpret_cast<const float2*>(src + (size_t)p * 512);
+    s0 += v.x;
+    s1 += v.y;
+  }
+  const float f0 = s0 / 49.0f, f1 = s1 / 49.0f;
+  if (feats) *reinterpret_cast<float2*>(feats + (size_t)b * 512 + tid * 2) = make_float2(f0, f1);
+  if (num_classes <= 0 || (!logits && !labels)) return;
+  for (int j = 0; j < num_classes; ++j) {
+    const float2 w = *reinterpret_cast<const float2*>(fc_w + (size_t)j * 512 + tid * 2);
+    float v = f0 * w.x + f1 * w.y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6][j] = v;
+  }
+  __syncthreads();
+  if (tid < num_classes) {
+    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + fc_b[tid];
+    lg[tid] = v;
+    if (logits) logits[(size_t)b * num_classes + tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0 && labels) {
+    int best = 0;
+    float bv = lg[0];
+    for (int j = 1; j < num_classes; ++j)
+      if (lg[j] > bv) {  // strict: first maximum wins, as torch.argmax
+        bv = lg[j];
+        best = j;
+      }
+    labels[b] = best;
+  }
+}
+
+int launch_head(const float* last, int n, const float* fc_w, const float* fc_b, int num_classes, float* feats,
+                float* logits, int64_t* labels, hipStream_t s) {
+  hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, s, last, fc_w, fc_b, num_classes, feats, logits,
+                     (long long*)labels);
+  return (int)hipGetLastError();
+}
+
+// NHWC (T or float) -> NCHW float32, test tap only.
+template <typename T>
+__global__ __launch_bounds__(256) void tap_export_kernel(const T* __restrict__ src, float* __restrict__ dst, int n,
+                                                         int C, int H, int W) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * C * H * W;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  long long t = gid / C;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const int b = (int)(t / H);
+  dst[(((size_t)b * C + c) * H + h) * W + w] = (float)src[gid];
+}
+
+int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, int H, int W, float* dst,
+                      hipStream_t s) {
+  const long long total = (long long)n * C * H * W;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (is_f32)
+    hipLaunchKernelGGL((tap_export_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, dst, n, C, H, W);
+  else if (precision == HIPAC_PREC_BF16)
+    hipLaunchKernelGGL((tap_export_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, dst, n, C, H,
+                       W);
+  else
+    hipLaunchKernelGGL((tap_export_kernel<_Float16>), dim3(grid), dim3(256), 0, s, (const _Float16*)src, dst, n, C,
+                       H, W);
+  return (int)hipGetLastError();
+}
+
+// ---- packing ------------------------------------------------------------------------
+
+static int upload(const void* host, size_t bytes, void** dev) {
+  HIPAC_CHECK_HIP(hipMalloc(dev, bytes));
+  HIPAC_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Fold BN and repack one conv: src [Cout][Cin][ks][ks] -> dst [Cout][ks][ks][Cin].
+static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float eps, int precision, bool stem,
+                     ConvW* out) {
+  HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
+                "pack: null tensor pointer (cout=%d cin=%d ks=%d)", cout, cin, ks);
+  const int K = stem ? 7 * 32 : ks * ks * cin;
+  std::vector<uint16_t> w((size_t)cout * K, 0);
+  std::vector<float> bias(cout);
+  for (int o = 0; o < cout; ++o) {
+    const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
+    bias[o] = (float)((double)c.bn_beta[o] - (double)c.bn_mean[o] * scale);
+    for (int i = 0; i < cin; ++i)
+      for (int kh = 0; kh < ks; ++kh)
+        for (int kw = 0; kw < ks; ++kw) {
+          const float v = (float)((double)c.conv_w[(((size_t)o * cin + i) * ks + kh) * ks + kw] * scale);
+          const size_t k = stem ? (size_t)kh * 32 + kw * 4 + i : ((size_t)kh * ks + kw) * cin + i;
+          w[(size_t)o * K + k] = to_bits(v, precision);
+        }
+  }
+  int rc = upload(w.data(), w.size() * 2, &out->w);
+  if (rc) return rc;
+  return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
+}
+
+static void free_convw(ConvW& c) {
+  if (c.w) (void)hipFree(c.w);
+  if (c.bias) (void)hipFree(c.bias);
+  c.w = nullptr;
+  c.bias = nullptr;
+}
+
+}  // namespace hipac
+
+using namespace hipac;
+
+struct hipac_weights {
+  Net net;
+};
+
+extern "C" {
+
+int hipac_abi_version(void) { return HIPAC_ABI_VERSION; }
+const char* hipac_last_error(void) { return g_err; }
+
+void hipac_weights_free(hipac_weights_t* w) {
+  if (!w) return;
+  free_convw(w->net.stem);
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 2; ++j) free_convw(w->net.block[i][j]);
+  for (int i = 0; i < 3; ++i) free_convw(w->net.down[i]);
+  if (w->net.fc_w) (void)hipFree(w->net.fc_w);
+  if (w->net.fc_b) (void)hipFree(w->net.fc_b);
+  delete w;
+}
+
+int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hipac_weights_t** out) {
+  HIPAC_REQUIRE(params && out, HIPAC_EINVAL, "pack: null argument");
+  HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16, HIPAC_EINVAL,
+                "pack: unknown precision %d", precision);
+  HIPAC_REQUIRE(params->num_classes >= 0 && params->num_classes <= 16, HIPAC_EINVAL,
+                "pack: num_classes %d out of range", params->num_classes);
+  HIPAC_REQUIRE((params->num_classes == 0) == (params->fc_w == nullptr), HIPAC_EINVAL,
+                "pack: fc_w / num_classes mismatch");
+  hipac_weights_t* w = new hipac_weights_t();
+  memset(&w->net, 0, sizeof(Net));
+  w->net.precision = precision;
+  w->net.num_classes = params->num_classes;
+  const float eps = params->bn_eps;
+  int rc = pack_conv(params->stem, 64, 3, 7, eps, precision, true, &w->net.stem);
+  const int ch[4] = {64, 128, 256, 512};
+  for (int s = 0; s < 4 && !rc; ++s) {
+    const int cin = s == 0 ? 64 : ch[s - 1];
+    rc = pack_conv(params->block[2 * s][0], ch[s], cin, 3, eps, precision, false, &w->net.block[2 * s][0]);
+    if (!rc) rc = pack_conv(params->block[2 * s][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s][1]);
+    if (!rc) rc = pack_conv(params->block[2 * s + 1][0], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][0]);
+    if (!rc) rc = pack_conv(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][1]);
+    if (!rc && s > 0) rc = pack_conv(params->down[s - 1], ch[s], cin, 1, eps, precision, false, &w->net.down[s - 1]);
+  }
+  if (!rc && params->num_classes > 0) {
+    HIPAC_REQUIRE(params->fc_b != nullptr, HIPAC_EINVAL, "pack: fc_b is null");
+    rc = upload(params->fc_w, (size_t)params->num_classes * 512 * 4, (void**)&w->net.fc_w);
+    if (!rc) rc = upload(params->fc_b, (size_t)params->num_classes * 4, (void**)&w->net.fc_b);
+  }
+  if (rc) {
+    hipac_weights_free(w);
+    return rc;
+  }
+  *out = w;
+  return 0;
+}
+
+int hipac_weights_precision(const hipac_weights_t* w) { return w ? w->net.precision : HIPAC_EINVAL; }
+int hipac_weights_num_classes(const hipac_weights_t* w) { return w ? w->net.num_classes : HIPAC_EINVAL; }
+
+size_t hipac_resnet18_workspace_bytes(int batch, int precision) {
+  (void)precision;
+  if (batch <= 0) return 0;
+  return make_plan(batch).total;
+}
+
+int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, int in_layout, float* feats,
+                           float* logits, int64_t* labels, void* workspace, size_t workspace_bytes, void* stream) {
+  HIPAC_REQUIRE(w && x && workspace, HIPAC_EINVAL, "forward: null argument");
+  HIPAC_REQUIRE(batch > 0, HIPAC_EINVAL, "forward: batch %d", batch);
+  HIPAC_REQUIRE(in_layout == HIPAC_IN_NCHW_F32 || in_layout == HIPAC_IN_NHWC4_PAD, HIPAC_EINVAL,
+                "forward: unknown in_layout %d", in_layout);
+  HIPAC_REQUIRE(!(logits || labels) || w->net.num_classes > 0, HIPAC_EINVAL,
+                "forward: logits/labels requested but the weights carry no fc (fc = Identity)");
+  HIPAC_REQUIRE(((uintptr_t)workspace & 255) == 0, HIPAC_EINVAL, "forward: workspace must be 256-byte aligned");
+  HIPAC_REQUIRE(((uintptr_t)x & 15) == 0, HIPAC_EINVAL, "forward: x must be 16-byte aligned");
+  const Plan p = make_plan(batch);
+  HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
+                workspace_bytes, p.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const Net& net = w->net;
+  const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * 2;
+  for (int b0 = 0; b0 < batch; b0 += p.bc) {
+    const int bc = batch - b0 < p.bc ? batch - b0 : p.bc;
+    const void* xin = ws + p.xin;
+    if (in_layout == HIPAC_IN_NCHW_F32) {
+      int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)b0 * 3 * kPatch * kPatch, ws + p.xin, bc,
+                                    net.precision, s);
+      HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
+    } else {
+      // native layout: run the stem straight off the caller's buffer
+      xin = (const char*)x + (size_t)b0 * in_img_bytes;
+    }
+    int rc = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16(net, p, ws, xin, bc, s)
+                                               : run_trunk_f16(net, p, ws, xin, bc, s);
+    if (rc) return rc;
+    rc = launch_head((const float*)(ws + p.blk[7]), bc, net.fc_w, net.fc_b, net.num_classes,
+                     feats ? feats + (size_t)b0 * 512 : nullptr,
+                     logits ? logits + (size_t)b0 * net.num_classes : nullptr, labels ? labels + b0 : nullptr, s);
+    HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
+  }
+  return 0;
+}
+
+int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap, float* dst,
+                       void* stream) {
+  HIPAC_REQUIRE(w && workspace && dst, HIPAC_EINVAL, "tap: null argument");
+  const Plan p = make_plan(batch);
+  HIPAC_REQUIRE(batch > 0 && batch <= p.bc, HIPAC_EINVAL, "tap: batch %d exceeds one sub-batch (%d)", batch, p.bc);
+  HIPAC_REQUIRE(tap >= 0 && tap <= 9, HIPAC_EINVAL, "tap: index %d", tap);
+  const char* ws = (const char*)workspace;
+  const void* src;
+  int C, H, is_f32 = 0;
+  if (tap == 0) {
+    src = ws + p.stem, C = 64, H = 112;
+  } else if (tap == 1) {
+    src = ws + p.pool, C = 64, H = 56;
+  } else {
+    const int blk = tap - 2, st = blk / 2;
+    const int ch[4] = {64, 128, 256, 512}, hw[4] = {56, 28, 14, 7};
+    src = ws + p.blk[blk], C = ch[st], H = hw[st];
+    is_f32 = blk == 7;
+  }
+  int rc = launch_tap_export(src, is_f32, w->net.precision, batch, C, H, H, dst, (hipStream_t)stream);
+  HIPAC_REQUIRE(rc == 0, rc, "tap: launch failed (%d)", rc);
+  return 0;
+}
+
+}  // extern "C"
