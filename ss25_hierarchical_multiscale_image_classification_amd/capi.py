@@ -61,6 +61,7 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "hipac_resnet18_run_ops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hipac_resnet18_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hipac_resample_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "hipac_tile_preprocess": (
@@ -275,6 +276,12 @@ class PackedResNet18:
                 _ptr(feats), _ptr(logits), _ptr(labels), ws.data_ptr(), ws.numel(), _stream())
         _check(rc, "hipac_resnet18_forward")
         return feats, logits, labels
+
+    def run_ops(self, batch: int, first: int, last: int):
+        """Re-run trunk ops first..last on the activations of the last forward (profiling aid)."""
+        with torch.cuda.device(self._ws.device):
+            _check(self._lib.hipac_resnet18_run_ops(self.handle, self._ws.data_ptr(), self._ws.numel(), batch, first,
+                                                    last, _stream()), "hipac_resnet18_run_ops")
 
     def tap(self, batch: int, tap: int) -> torch.Tensor:
         """Intermediate activation of the last forward (float32 NCHW); tests only."""

@@ -88,8 +88,11 @@ struct Plan {
 Plan make_plan(int batch);
 
 // per-precision launchers (conv_bf16.hip / conv_f16.hip)
-int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s);
-int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s);
+int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
+                   int last);
+int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
+                  int last);
+constexpr int kNumOps = 22;
 
 // elementwise.hip
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);

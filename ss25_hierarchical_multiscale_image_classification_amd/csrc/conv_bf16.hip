@@ -1,7 +1,8 @@
 // bf16 instantiation of the ResNet18 trunk (separate TU so the two precisions compile in parallel).
 #include "conv_igemm.h"
 namespace hipac {
-int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s) {
-  return run_trunk<__bf16>(net, p, ws, xin, bc, s);
+int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
+                   int last) {
+  return run_trunk<__bf16>(net, p, ws, xin, bc, s, first, last);
 }
 }  // namespace hipac

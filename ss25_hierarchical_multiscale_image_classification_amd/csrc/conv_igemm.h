@@ -279,10 +279,22 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     }                            \
   } while (0)
 
+// The trunk is a fixed sequence of 22 launches ("ops"): 0 stem, 1 max-pool, then per
+// stage conv1(b0) [proj] conv2(b0) conv1(b1) conv2(b1).  `first..last` selects a
+// sub-range (whole trunk by default) so single layers can be timed / profiled.
+struct OpRange {
+  int first, last, next;
+  bool take() {
+    const int i = next++;
+    return i >= first && i <= last;
+  }
+};
+
 // One ResNet stage = two BasicBlocks.  CI/HI: input channels / spatial size,
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
 template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST>
-static int run_stage(const Net& net, int stage, const void* x, char* ws, const Plan& p, int bc, hipStream_t s) {
+static int run_stage(const Net& net, int stage, const void* x, char* ws, const Plan& p, int bc, hipStream_t s,
+                     OpRange& ops) {
   constexpr int HO = HI / STRIDE;
   void* tmp = ws + p.tmp;
   void* ds = ws + p.ds;
@@ -291,34 +303,42 @@ static int run_stage(const Net& net, int stage, const void* x, char* ws, const P
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   // block 0
-  HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, bc, s)));
+  if (ops.take())
+    HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, bc, s)));
   const void* idt = x;
   if constexpr (STRIDE != 1 || CI != CO) {
-    HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr,
-                                                                             ds, bc, s)));
+    if (ops.take())
+      HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr,
+                                                                               ds, bc, s)));
     idt = ds;
   }
-  HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, bc, s)));
+  if (ops.take())
+    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, bc, s)));
   // block 1
-  HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false>(o0, bw1[0], nullptr, tmp, bc, s)));
-  HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST>(tmp, bw1[1], o0, o1, bc, s)));
+  if (ops.take())
+    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false>(o0, bw1[0], nullptr, tmp, bc, s)));
+  if (ops.take())
+    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST>(tmp, bw1[1], o0, o1, bc, s)));
   return 0;
 }
 
 template <typename T>
-static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s) {
-  HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr,
-                                                                             ws + p.stem, bc, s)));
-  {
+static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s,
+                     int first, int last) {
+  OpRange ops{first, last, 0};
+  if (ops.take())
+    HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr,
+                                                                               ws + p.stem, bc, s)));
+  if (ops.take()) {
     const long long total = (long long)bc * 56 * 56 * 8;
     hipLaunchKernelGGL((maxpool3x3s2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        (const T*)(ws + p.stem), (T*)(ws + p.pool), bc);
     HIPAC_TRY((int)hipGetLastError());
   }
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws, p, bc, s)));
-  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws, p, bc, s)));
-  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws, p, bc, s)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws, p, bc, s)));
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws, p, bc, s, ops)));
+  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws, p, bc, s, ops)));
+  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws, p, bc, s, ops)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws, p, bc, s, ops)));
   return 0;
 }
 

@@ -325,8 +325,8 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
       // native layout: run the stem straight off the caller's buffer
       xin = (const char*)x + (size_t)b0 * in_img_bytes;
     }
-    int rc = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16(net, p, ws, xin, bc, s)
-                                               : run_trunk_f16(net, p, ws, xin, bc, s);
+    int rc = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16(net, p, ws, xin, bc, s, 0, kNumOps)
+                                               : run_trunk_f16(net, p, ws, xin, bc, s, 0, kNumOps);
     if (rc) return rc;
     rc = launch_head((const float*)(ws + p.blk[7]), bc, net.fc_w, net.fc_b, net.num_classes,
                      feats ? feats + (size_t)b0 * 512 : nullptr,
@@ -334,6 +334,21 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
     HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
   }
   return 0;
+}
+
+int hipac_resnet18_run_ops(const hipac_weights_t* w, void* workspace, size_t workspace_bytes, int batch,
+                           int first_op, int last_op, void* stream) {
+  HIPAC_REQUIRE(w && workspace, HIPAC_EINVAL, "run_ops: null argument");
+  const Plan p = make_plan(batch);
+  HIPAC_REQUIRE(batch > 0 && batch <= p.bc, HIPAC_EINVAL, "run_ops: batch %d exceeds one sub-batch (%d)", batch, p.bc);
+  HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "run_ops: workspace %zu < required %zu",
+                workspace_bytes, p.total);
+  HIPAC_REQUIRE(first_op >= 0 && first_op <= last_op && last_op < kNumOps, HIPAC_EINVAL, "run_ops: range %d..%d",
+                first_op, last_op);
+  char* ws = (char*)workspace;
+  return w->net.precision == HIPAC_PREC_BF16
+             ? run_trunk_bf16(w->net, p, ws, ws + p.xin, batch, (hipStream_t)stream, first_op, last_op)
+             : run_trunk_f16(w->net, p, ws, ws + p.xin, batch, (hipStream_t)stream, first_op, last_op);
 }
 
 int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap, float* dst,

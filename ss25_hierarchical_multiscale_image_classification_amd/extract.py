@@ -1,0 +1,247 @@
+"""Sliding-window patch extraction over a device-resident slide pyramid.
+
+Mirrors ``extract_patches`` (src/main.py:609-732) and ``parse_xml_mask``
+(src/main.py:372-410): same level -> window-size table, the same (quirky) stride,
+x-outer / y-inner order, border padding with white, whiteness filter, tumour label
+from the annotation mask, level-L pixel coordinates in the names.  The per-window
+pixel work (crop, pad, whiteness sum, resize to 224, normalise) runs in the HIP
+kernel ``hipac_tile_preprocess`` on the slide as it sits in HBM; only the loop
+bounds and the polygon rasterisation (Pillow) stay on the host.
+"""
+from __future__ import annotations
+
+import os
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import capi, synth
+
+PATCH_SIZES = {0: 1792, 1: 896, 2: 448, 3: 224}  # src/main.py:614
+LABEL_NAMES = {0: "normal", 1: "tumor"}  # src/datasets/patch_dataset.py:15
+
+
+def window_grid(width: int, height: int, level: int, stride: Optional[int] = None, pad: bool = True):
+    """Loop bounds of src/main.py:611-615, :658-665, :682-691.  Returns
+    (patch_size, stride, xy int32[n,2]) with windows in the reference's visiting order
+    (x outer, y inner).  ``stride=None`` keeps the reference's behaviour: the default
+    ``patch_size=224`` is what ``stride = stride or patch_size`` sees (:611), so the
+    stride is 224 at every level; pass ``stride=PATCH_SIZES[level]`` for the
+    non-overlapping grid the README describes."""
+    patch_size = 224
+    stride = stride or patch_size
+    patch_size = PATCH_SIZES.get(level, 224)
+    pad_w = (patch_size - width % patch_size) % patch_size if pad else 0
+    pad_h = (patch_size - height % patch_size) % patch_size if pad else 0
+    xs = np.arange(0, width + pad_w, stride, dtype=np.int64)
+    ys = np.arange(0, height + pad_h, stride, dtype=np.int64)
+    xs, ys = xs[xs < width], ys[ys < height]
+    xy = np.stack([np.repeat(xs, len(ys)), np.tile(ys, len(xs))], axis=1).astype(np.int32)
+    return patch_size, stride, xy
+
+
+def parse_annotation_xml(xml_path: str) -> List[List[Tuple[float, float]]]:
+    """The XML walk of src/main.py:395-407 (ASAP format: every
+    ``Annotation/Coordinates`` node, ``Coordinate`` children with X / Y attributes in
+    level-0 pixels) with the standard library instead of lxml."""
+    tree = ET.parse(xml_path)
+    polys = []
+    for ann in tree.getroot().iter("Annotation"):
+        node = ann.find("Coordinates")
+        if node is None:
+            continue
+        pts = []
+        for c in node.findall("Coordinate"):
+            try:
+                pts.append((float(c.get("X")), float(c.get("Y"))))
+            except (TypeError, ValueError):
+                continue
+        if pts:
+            polys.append(pts)
+    return polys
+
+
+def rasterize_mask(polygons_l0, level_dims: Tuple[int, int], base_dims: Tuple[int, int]) -> np.ndarray:
+    """src/main.py:387-410: scale level-0 polygon vertices by level/base dims, truncate
+    with int(), fill + outline with 255 on an 'L' image of the level's size.
+    Returns uint8[H,W]."""
+    from PIL import Image, ImageDraw
+
+    sx, sy = level_dims[0] / base_dims[0], level_dims[1] / base_dims[1]
+    mask = Image.new("L", level_dims, 0)
+    draw = ImageDraw.Draw(mask)
+    for poly in polygons_l0:
+        pts = [(int(float(x) * sx), int(float(y) * sy)) for x, y in poly]
+        if pts:
+            draw.polygon(pts, outline=255, fill=255)
+    return np.array(mask)
+
+
+class DeviceSlide:
+    """A slide pyramid resident in HBM: per level a uint8[H, Wpad, 3] tensor whose row
+    pitch is a multiple of 48 bytes (16 pixels) so the preprocess kernel can use
+    16-byte loads.  Exposes the two openslide attributes the reference reads
+    (``level_dimensions``, ``level_downsamples``, src/main.py:654-655)."""
+
+    def __init__(self, levels: Sequence[torch.Tensor], device: torch.device | str = "cuda", name: str = "slide"):
+        dev = torch.device(device)
+        self.name = name
+        self.level_dimensions = tuple((int(l.shape[1]), int(l.shape[0])) for l in levels)
+        self.level_downsamples = tuple(self.level_dimensions[0][0] / d[0] for d in self.level_dimensions)
+        self.levels: List[torch.Tensor] = []
+        for l in levels:
+            if l.dtype != torch.uint8 or l.dim() != 3 or l.shape[2] != 3:
+                raise capi.HipacError("levels must be uint8[H,W,3]")
+            h, w = int(l.shape[0]), int(l.shape[1])
+            wp = (w + 15) // 16 * 16
+            buf = torch.empty((h, wp, 3), dtype=torch.uint8, device=dev)
+            buf[:, :w] = l.to(dev)
+            if wp > w:
+                buf[:, w:] = 0
+            self.levels.append(buf)
+        self.device = dev
+        self.polygons: Optional[list] = None
+        self._masks: Dict[int, torch.Tensor] = {}
+
+    @classmethod
+    def synthetic(cls, width: int, height: int, seed: int = 2, n_levels: int = 4, device="cuda",
+                  with_polygons: bool = True, name: Optional[str] = None):
+        l0 = synth.synth_level0(width, height, seed=seed, device=device)
+        s = cls(synth.build_pyramid(l0, n_levels), device=device, name=name or f"synthetic_{seed}")
+        if with_polygons:
+            s.polygons = synth.synth_polygons(width, height, seed=seed)
+        return s
+
+    def mask(self, level: int) -> Optional[torch.Tensor]:
+        if self.polygons is None:
+            return None
+        if level not in self._masks:
+            m = rasterize_mask(self.polygons, self.level_dimensions[level], self.level_dimensions[0])
+            self._masks[level] = torch.from_numpy(m).to(self.device)
+        return self._masks[level]
+
+
+@dataclass
+class LevelScan:
+    """Everything the extractor decides for one level, on device, in visiting order."""
+    level: int
+    patch_size: int
+    xy: torch.Tensor      # int32[n,2]
+    sums: torch.Tensor    # int32[n] (uint32 bit pattern)
+    keep: torch.Tensor    # uint8[n]
+    labels: torch.Tensor  # uint8[n]
+
+    def names(self, prefix: str) -> List[str]:
+        """File names the reference would have written (src/main.py:722), kept windows only."""
+        xy = self.xy.cpu().numpy()
+        keep = self.keep.cpu().numpy().astype(bool)
+        lab = self.labels.cpu().numpy()
+        return [f"{prefix}_x{x}_y{y}_{LABEL_NAMES[int(l)]}.png" for (x, y), k, l in zip(xy, keep, lab) if k]
+
+
+def iter_level(slide: DeviceSlide, level: int, out_format: str = "bf16", batch_windows: int = 512,
+               stride: Optional[int] = None, pad: bool = True, kept_only: bool = True) -> Iterator[dict]:
+    """Stream one level: for each batch of windows run the preprocess kernel and yield
+    {"x": network input (kept windows only when ``kept_only``), "xy", "sums", "keep",
+    "labels"} -- all device tensors."""
+    width, height = slide.level_dimensions[level]
+    P, _, xy_np = window_grid(width, height, level, stride, pad)
+    img = slide.levels[level]
+    mask = slide.mask(level)
+    for i0 in range(0, len(xy_np), batch_windows):
+        xy = torch.from_numpy(xy_np[i0 : i0 + batch_windows]).to(slide.device)
+        out, sums, keep = capi.tile_preprocess(img, xy, P, out_format, width=width)
+        if mask is not None:
+            labels = capi.window_labels(mask, xy, P)
+        else:
+            labels = torch.zeros((xy.shape[0],), dtype=torch.uint8, device=slide.device)
+        if kept_only:
+            idx = torch.nonzero(keep, as_tuple=False).flatten()
+            out = out.index_select(0, idx)
+        yield {"x": out, "xy": xy, "sums": sums, "keep": keep, "labels": labels}
+
+
+def scan_level(slide: DeviceSlide, level: int, **kw) -> LevelScan:
+    """Decisions only (no pixels kept): the device-side equivalent of one
+    ``extract_patches(level=...)`` pass over one slide."""
+    parts = list(iter_level(slide, level, out_format=kw.pop("out_format", "u8"), kept_only=True, **kw))
+    P = PATCH_SIZES.get(level, 224)
+    cat = lambda k: torch.cat([p[k] for p in parts]) if parts else torch.empty(0)
+    return LevelScan(level, P, cat("xy"), cat("sums"), cat("keep"), cat("labels"))
+
+
+class WSIPatchStream:
+    """Iterable over (x, meta) device batches of KEPT windows for the fused path:
+    x in the network's native layout, meta int32[B,4] = (level, x, y, label)."""
+
+    def __init__(self, slide: DeviceSlide, levels: Sequence[int] = (0, 1, 2, 3), batch_windows: int = 512,
+                 precision: str = "bf16", stride: Optional[int] = None):
+        self.slide, self.levels, self.batch_windows = slide, tuple(levels), batch_windows
+        self.precision, self.stride = precision, stride
+
+    def __iter__(self):
+        for level in self.levels:
+            for part in iter_level(self.slide, level, out_format=self.precision, batch_windows=self.batch_windows,
+                                   stride=self.stride):
+                idx = torch.nonzero(part["keep"], as_tuple=False).flatten()
+                xy = part["xy"].index_select(0, idx)
+                lab = part["labels"].index_select(0, idx).to(torch.int32)
+                meta = torch.cat([torch.full_like(lab, level)[:, None], xy, lab[:, None]], dim=1)
+                yield part["x"], meta
+
+
+@torch.no_grad()
+def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[int] = (0, 1, 2, 3),
+                batch_windows: int = 512, stride: Optional[int] = None, want_logits: bool = True):
+    """Whole-slide hierarchical scan: windows -> preprocess -> ResNet18 -> per-patch
+    features / logits / labels.  Returns device tensors (feats[n,512], logits[n,C] or
+    None, pred int64[n] or None, meta int32[n,4])."""
+    feats, logits, preds, metas = [], [], [], []
+    has_fc = net.num_classes > 0 and want_logits
+    for x, meta in WSIPatchStream(slide, levels, batch_windows, net.precision, stride):
+        if x.shape[0] == 0:
+            continue
+        f, l, p = net.forward(x, want_feats=True, want_logits=has_fc, want_labels=has_fc, native_layout=True)
+        feats.append(f)
+        metas.append(meta)
+        if has_fc:
+            logits.append(l)
+            preds.append(p)
+    dev = slide.device
+    if not feats:
+        return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
+    return (torch.cat(feats), torch.cat(logits) if has_fc else None, torch.cat(preds) if has_fc else None,
+            torch.cat(metas))
+
+
+def save_patch_pngs(slide: DeviceSlide, level: int, out_dir: str, stride: Optional[int] = None) -> int:
+    """Optional reference-compatible output: write every kept window as
+    ``<out_dir>/<slide>/<slide>_x{x}_y{y}_{label}.png`` (src/main.py:722-726).  This is
+    the slow, host-bound leg (D2H copy + PNG encode) kept for downstream tools; the fused
+    path never touches disk (PNG is lossless, so skipping it changes nothing)."""
+    from PIL import Image
+
+    scan = scan_level(slide, level, stride=stride)
+    P = scan.patch_size
+    width, height = slide.level_dimensions[level]
+    img = slide.levels[level]
+    save_dir = os.path.join(out_dir, slide.name)
+    os.makedirs(save_dir, exist_ok=True)
+    xy = scan.xy.cpu().numpy()
+    keep = scan.keep.cpu().numpy().astype(bool)
+    lab = scan.labels.cpu().numpy()
+    n = 0
+    for (x, y), k, l in zip(xy, keep, lab):
+        if not k:
+            continue
+        path = os.path.join(save_dir, f"{slide.name}_x{x}_y{y}_{LABEL_NAMES[int(l)]}.png")
+        if not os.path.exists(path):
+            canvas = np.full((P, P, 3), 255, np.uint8)
+            pw, ph = min(P, width - x), min(P, height - y)
+            canvas[:ph, :pw] = img[y : y + ph, x : x + pw].cpu().numpy()
+            Image.fromarray(canvas, "RGB").save(path)
+        n += 1
+    return n

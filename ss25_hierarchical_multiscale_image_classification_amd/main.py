@@ -1,0 +1,190 @@
+"""Command line mirroring the hot-path flags of the reference's ``src/main.py``
+(:1073-1166): ``--patch``, ``--patch_level {0,1,2,3,all}``, ``--extract_features``,
+``--train``, ``--train_strategy``, ``--strategy {balanced,weighted_loss,self_supervised}``.
+
+Layout under ``--data_root`` (default ``./data/camelyon16``, README.md:142-164):
+    train/img/<slide>.{npz,tif}      slides   (.npz: keys level0..levelN uint8[H,W,3])
+    train/mask/annotations/<slide>.xml
+    patches/level_L/<slide>/...      extractor output
+Outputs of ``--extract_features`` are written to the current directory exactly like
+the reference (patch_features_L.npy, patch_labels_L.npy, patch_paths_L.txt).
+
+Additive flags: ``--data_root``, ``--synthetic W,H,SEED[,NAME]`` (repeatable; a slide
+made on the GPU instead of a file), ``--write_png`` (also emit the reference's PNG
+tree), ``--precision {bf16,fp16}``, ``--weights PATH``, ``--stride N``.
+
+Everything outside the hot path (download, FROC, plots, MIL) is out of scope and the
+corresponding reference flags are accepted but answered with a clear message.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+OUT_OF_SCOPE = ("download", "remote", "prepare", "validation", "validate", "evaluate", "run_evaluation",
+                "balance_dataset", "count_tumor_patches", "patch_one_slide", "slide", "move_files",
+                "check_good_downloaded_files")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="HiPAC hot path on MI355X (patch extraction + ResNet18 scoring)")
+    # --- the reference's surface (src/main.py:1075-1093) ---
+    p.add_argument("-p", "--patch", action="store_true", help="Extract patches")
+    p.add_argument("--patch_level", type=str, default="3", help="WSI level (0, 1, 2, 3, or 'all')")
+    p.add_argument("--extract_features", action="store_true", help="Extract features from patches")
+    p.add_argument("-train", "--train", action="store_true", help="Train ResNet18 patch classifier")
+    p.add_argument("--train_strategy", action="store_true", help="Train with a specific strategy")
+    p.add_argument("--strategy", type=str, default="self_supervised",
+                   choices=["balanced", "weighted_loss", "self_supervised"])
+    for name in OUT_OF_SCOPE:
+        if name in ("patch_one_slide", "slide"):
+            p.add_argument(f"--{name}", type=str, default=None, help="(reference flag; out of scope here)")
+        else:
+            p.add_argument(f"--{name}", action="store_true", help="(reference flag; out of scope here)")
+    # --- additive ---
+    p.add_argument("--data_root", type=str, default=None)
+    p.add_argument("--synthetic", action="append", default=[], metavar="W,H,SEED[,NAME]")
+    p.add_argument("--write_png", action="store_true")
+    p.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
+    p.add_argument("--weights", type=str, default=None, help="state_dict (.pth, any reference key layout)")
+    p.add_argument("--stride", type=int, default=None, help="window stride (default: the reference's 224)")
+    p.add_argument("--epochs", type=int, default=None)
+    p.add_argument("--batch_size", type=int, default=512)  # BATCH_SIZE, src/main.py:46
+    return p
+
+
+def data_root(args) -> str:
+    return args.data_root or os.path.join(os.getcwd(), "data", "camelyon16")
+
+
+def levels_of(args) -> List[int]:
+    return [0, 1, 2, 3] if args.patch_level == "all" else [int(args.patch_level)]
+
+
+def open_slides(args):
+    """Yield DeviceSlide objects: synthetic specs first, then files in train/img."""
+    from .extract import DeviceSlide, parse_annotation_xml
+
+    for spec in args.synthetic:
+        parts = spec.split(",")
+        w, h, seed = int(parts[0]), int(parts[1]), int(parts[2])
+        yield DeviceSlide.synthetic(w, h, seed=seed, name=parts[3] if len(parts) > 3 else f"synthetic_{seed}")
+    img_dir = os.path.join(data_root(args), "train", "img")
+    if not os.path.isdir(img_dir):
+        return
+    ann_dir = os.path.join(data_root(args), "train", "mask", "annotations")
+    for file in sorted(os.listdir(img_dir)):
+        stem, ext = os.path.splitext(file)
+        if ext == ".npz":
+            z = np.load(os.path.join(img_dir, file))
+            levels = [torch.from_numpy(z[f"level{i}"]) for i in range(len(z.files)) if f"level{i}" in z.files]
+            slide = DeviceSlide(levels, name=stem)
+        elif ext == ".tif":
+            raise SystemExit(f"[ERROR] {file}: reading TIFF pyramids needs openslide, which is not available "
+                             "here; convert the slide to .npz levels or use --synthetic")
+        else:
+            continue
+        xml = os.path.join(ann_dir, stem + ".xml")
+        if os.path.exists(xml):
+            slide.polygons = parse_annotation_xml(xml)
+        yield slide
+
+
+def cmd_patch(args):
+    from .extract import save_patch_pngs, scan_level
+
+    for slide in open_slides(args):
+        for level in levels_of(args):
+            level_dir = os.path.join(data_root(args), "patches", f"level_{level}")
+            save_dir = os.path.join(level_dir, slide.name)
+            if os.path.isdir(save_dir) and os.listdir(save_dir):  # src/main.py:634-640
+                print(f"[INFO] Patches for {slide.name} already extracted, skipping.")
+                continue
+            os.makedirs(save_dir, exist_ok=True)
+            scan = scan_level(slide, level, stride=args.stride)
+            np.savez(os.path.join(save_dir, "manifest.npz"), xy=scan.xy.cpu().numpy(),
+                     keep=scan.keep.cpu().numpy(), labels=scan.labels.cpu().numpy(),
+                     sums=scan.sums.cpu().numpy().astype(np.uint32), patch_size=scan.patch_size, level=level)
+            n = int(scan.keep.sum().item())
+            if args.write_png:
+                save_patch_pngs(slide, level, level_dir, stride=args.stride)
+            print(f"[INFO] Patch extraction complete for {slide.name} at level {level}. Total patches: {n}")
+
+
+def load_net(args, num_classes: Optional[int] = None):
+    from . import capi, synth
+    from .weights import canonical_state_dict
+
+    if args.weights:
+        sd = canonical_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
+    else:
+        print("[WARNING] no --weights given: using seeded random-init ResNet18 "
+              "(the reference's own transplant loads nothing either, SURVEY.md F4)")
+        sd = synth.seeded_resnet18_state_dict(0, num_classes=num_classes)
+    if num_classes is None:
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+    return capi.PackedResNet18(sd, precision=args.precision)
+
+
+def cmd_extract_features(args):
+    from .features import extract_features_from_pngs, extract_features_from_slide, save_feature_files
+
+    level = int(args.patch_level) if args.patch_level != "all" else 3  # src/main.py:1134
+    net = load_net(args, num_classes=None)
+    patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
+    has_png = os.path.isdir(patch_dir) and any(
+        f.endswith(".png") for _, _, fs in os.walk(patch_dir) for f in fs)
+    if has_png:
+        feats, labels, paths = extract_features_from_pngs(patch_dir, net, batch_size=args.batch_size)
+    else:
+        fs, ls, ps = [], [], []
+        for slide in open_slides(args):
+            f, l, p = extract_features_from_slide(slide, net, level, stride=args.stride)
+            fs.append(f), ls.append(l), ps.extend(p)
+        if not fs:
+            print(f"[ERROR] Patches must be extracted at level {level} before extracting features.")
+            return 1
+        feats, labels, paths = torch.cat(fs), np.concatenate(ls), ps
+    save_feature_files(level, feats.numpy(), labels, paths)
+    print(f"[INFO] Features saved to patch_features_{level}.npy ({feats.shape[0]} patches)")
+    return 0
+
+
+def cmd_train(args, strategy: Optional[str]):
+    from .train import train_resnet_classifier
+
+    level = int(args.patch_level) if args.patch_level != "all" else 3
+    patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
+    if not (os.path.isdir(patch_dir) and os.listdir(patch_dir)):
+        print("[ERROR] Patches must be extracted before training.")
+        return 1
+    train_resnet_classifier(patch_dir, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size,
+                            precision=args.precision)
+    return 0
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    for name in OUT_OF_SCOPE:
+        if getattr(args, name):
+            print(f"[ERROR] --{name} is outside the accelerated hot path (see DESIGN.md 'Out of scope').")
+            return 2
+    rc = 0
+    if args.patch:
+        cmd_patch(args)
+    if args.extract_features:
+        rc = cmd_extract_features(args) or rc
+    if args.train:
+        rc = cmd_train(args, None) or rc
+    if args.train_strategy:
+        rc = cmd_train(args, args.strategy) or rc
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,108 @@
+"""world_size-2 (and 3) gloo tests of the multi-GPU plumbing: slide sharding, ragged
+all-gather in rank order == single-process order, differentiable gather for NT-Xent."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ss25_hierarchical_multiscale_image_classification_amd import dist as hdist
+from ss25_hierarchical_multiscale_image_classification_amd.simclr import nt_xent_loss
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    hdist.init_from_env("gloo")
+    try:
+        out[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, fn):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, out), nprocs=world, join=True)
+    return [out[r] for r in range(world)]
+
+
+def _units(n_units):
+    """Deterministic fake per-slide results with ragged row counts (incl. an empty slide)."""
+    res = []
+    for u in range(n_units):
+        n = [5, 0, 3, 7, 1][u % 5]
+        g = torch.Generator().manual_seed(u)
+        res.append((torch.randn(n, 512, generator=g), torch.randn(n, 2, generator=g),
+                    torch.stack([torch.full((n,), u), torch.arange(n), torch.arange(n) * 2, torch.zeros(n)], 1).int()))
+    return res
+
+
+def _gather_job(rank, world):
+    units = _units(5)
+    mine = hdist.shard_units(5, rank, world)
+    cat = lambda i: torch.cat([units[u][i] for u in mine]) if mine else units[0][i][:0]
+    f, l, m = hdist.gather_results(cat(0), cat(1), cat(2))
+    return f.numpy(), l.numpy(), m.numpy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_results_is_rank_major_concatenation(world):
+    outs = _run(world, _gather_job)
+    units = _units(5)
+    order = [u for r in range(world) for u in hdist.shard_units(5, r, world)]
+    exp = [torch.cat([units[u][i] for u in order]).numpy() for i in range(3)]
+    for f, l, m in outs:  # every rank holds the same, complete result
+        assert np.array_equal(f, exp[0]) and np.array_equal(l, exp[1]) and np.array_equal(m, exp[2])
+    # same rows as the single-process run, keyed by (slide, row)
+    single = torch.cat([u[2] for u in units]).numpy()
+    assert sorted(map(tuple, outs[0][2])) == sorted(map(tuple, single))
+
+
+def test_column_sharding_reproduces_single_process_order():
+    for n_cols in (1, 7, 224):
+        for world in (1, 2, 3, 8):
+            spans = [hdist.shard_columns(n_cols, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n_cols
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _ntxent_job(rank, world):
+    n_local, d = 3, 16
+    g = torch.Generator().manual_seed(0)
+    zi_all = torch.randn(world * n_local, d, generator=g)
+    zj_all = torch.randn(world * n_local, d, generator=g)
+    sl = slice(rank * n_local, (rank + 1) * n_local)
+    zi, zj = zi_all[sl].clone().requires_grad_(True), zj_all[sl].clone().requires_grad_(True)
+    loss = nt_xent_loss(zi, zj, 0.5, gather=hdist.gather_with_grad)
+    loss.backward()
+    return loss.item(), zi.grad.numpy(), zj.grad.numpy()
+
+
+def test_global_batch_nt_xent_matches_single_process():
+    """negatives come from the WHOLE batch; grads equal the single-process ones."""
+    world, n_local, d = 2, 3, 16
+    outs = _run(world, _ntxent_job)
+    g = torch.Generator().manual_seed(0)
+    zi = torch.randn(world * n_local, d, generator=g).requires_grad_(True)
+    zj = torch.randn(world * n_local, d, generator=g).requires_grad_(True)
+    loss = nt_xent_loss(zi, zj, 0.5)
+    loss.backward()
+    for r, (l, gi, gj) in enumerate(outs):
+        assert abs(l - loss.item()) < 1e-6
+        sl = slice(r * n_local, (r + 1) * n_local)
+        # each rank computed the full loss, so summing over ranks' identical losses scales grads by world
+        assert np.allclose(gi, zi.grad[sl].numpy() * world, atol=1e-5)
+        assert np.allclose(gj, zj.grad[sl].numpy() * world, atol=1e-5)

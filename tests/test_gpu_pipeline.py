@@ -1,0 +1,61 @@
+"""End-to-end: slide in HBM -> windows -> preprocess -> ResNet18 -> per-patch results,
+against the oracle's extractor + transform + network on the same seeded slide."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import extractor_ref as E, resnet18_ref as R, transform_ref as T
+from ss25_hierarchical_multiscale_image_classification_amd import capi, extract, features, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_score_slide_matches_oracle_pipeline():
+    W, H, seed = 1900, 1850, 21
+    l0 = synth.synth_level0(W, H, seed=seed, n_blobs=4)
+    levels = synth.build_pyramid(l0, 4)
+    polys = synth.synth_polygons(W, H, seed=seed)
+    slide = extract.DeviceSlide(levels, device="cuda", name="tumor_901")
+    slide.polygons = polys
+    sd = synth.seeded_resnet18_state_dict(4, num_classes=2)
+    net = capi.PackedResNet18(sd, precision="fp16")
+    feats, logits, preds, meta = extract.score_slide(slide, net, levels=(1, 2, 3), batch_windows=7)
+    ref_slide = E.ArraySlide([l.numpy() for l in levels])
+    rows, ref_x = [], []
+    for level in (1, 2, 3):
+        wins, pix = E.extract_patches_ref(ref_slide, level, polygons_l0=polys)
+        for w, p in zip([w for w in wins if w.keep], pix):
+            rows.append((level, w.x, w.y, w.label))
+            ref_x.append(torch.from_numpy(T.eval_transform(p)))
+    assert np.array_equal(meta.cpu().numpy(), np.array(rows, np.int32))  # same windows, same order
+    ref_f, ref_l = R.resnet18_forward(torch.stack(ref_x), sd)
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(feats, ref_f) <= 2.5e-3 and rel(logits, ref_l) <= 2.5e-3
+    margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
+    decided = margin > 2 * 2.5e-3 * ref_l.abs().max()
+    assert torch.equal(preds.cpu()[decided], ref_l.argmax(1)[decided])
+    # the fused feature-extraction entry point names patches like the reference (main.py:722)
+    f3, lab3, paths = features.extract_features_from_slide(slide, net, 3)
+    n3 = sum(1 for r in rows if r[0] == 3)
+    assert f3.shape == (n3, 512) and len(paths) == n3 and lab3.dtype == np.int64
+    first = next(r for r in rows if r[0] == 3)
+    assert paths[0] == f"tumor_901/tumor_901_x{first[1]}_y{first[2]}_{'tumor' if first[3] else 'normal'}.png"
+
+
+def test_png_tree_flow_equals_fused_flow(tmp_path):
+    """extract_patches -> PNG tree -> PatchDataset -> features == fused features
+    (PNG is lossless), compared keyed by path because the loader shuffles."""
+    W, H, seed = 1500, 1300, 33
+    slide = extract.DeviceSlide(synth.build_pyramid(synth.synth_level0(W, H, seed=seed, n_blobs=3), 4),
+                                device="cuda", name="normal_777")
+    net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=None), precision="bf16")
+    level = 2
+    n = extract.save_patch_pngs(slide, level, str(tmp_path))
+    assert n > 0
+    f_png, lab_png, paths_png = features.extract_features_from_pngs(str(tmp_path), net, batch_size=5, num_workers=0)
+    f_fused, lab_fused, paths_fused = features.extract_features_from_slide(slide, net, level)
+    assert len(paths_png) == len(paths_fused) == n
+    by_name = {p.split("/")[-1]: i for i, p in enumerate(paths_fused)}
+    order = [by_name[p.replace("\\", "/").split("/")[-1]] for p in paths_png]
+    assert torch.equal(f_png, f_fused[order])
+    assert np.array_equal(lab_png, lab_fused[order])

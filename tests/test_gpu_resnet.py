@@ -1,0 +1,154 @@
+"""Parity of the HIP ResNet18 forward (through the C ABI) against the oracle and the
+committed golden vectors.
+
+Tolerances (norm-relative: max|a-b| / max|b| per tensor), with the values measured on
+MI355X in round 1 in brackets -- the arithmetic is fp32-accumulated MFMA on operands
+rounded to the named type, so the error is rounding only and grows ~sqrt(depth):
+    fp16 : features 2.5e-3 [5e-4]   logits 2.5e-3 [9e-4]   intermediate taps 3e-3 [<=1.3e-3]
+    bf16 : features 2.5e-2 [4e-3]   logits 2.5e-2 [7e-3]   intermediate taps 3e-2 [<=1.0e-2]
+north_star's 1e-3 (fp32-relative) is met by the fp16 mode on the logits; bf16 (the
+BASELINE dtype) cannot meet it by construction (8-bit mantissa) -- see DESIGN.md.
+Labels must be identical wherever the oracle's margin |l0-l1| exceeds twice the
+logit error bound; near-ties are counted and reported, not hidden.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import resnet18_ref as R, transform_ref as T
+from ss25_hierarchical_multiscale_image_classification_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp16": dict(out=2.5e-3, tap=3e-3), "bf16": dict(out=2.5e-2, tap=3e-2)}
+TAPS = ["stem", "maxpool"] + [f"layer{s}.{k}" for s in (1, 2, 3, 4) for k in (0, 1)]
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(f"{golden_dir}/resnet_golden.npz")
+
+
+def golden_sd(golden, seed):
+    sd = synth.seeded_resnet18_state_dict(seed, num_classes=2)
+    sd["fc.weight"] = torch.from_numpy(golden[f"s{seed}_fc_w"])
+    sd["fc.bias"] = torch.from_numpy(golden[f"s{seed}_fc_b"])
+    return sd
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_golden_features_logits_labels(golden, prec, seed):
+    u8 = torch.from_numpy(golden["patches_u8"]).cuda()
+    x = capi.patches_normalize(u8, "nchw_f32")
+    net = capi.PackedResNet18(golden_sd(golden, seed), precision=prec)
+    f, l, lab = net.forward(x, want_feats=True, want_logits=True, want_labels=True)
+    ref_f, ref_l = golden[f"s{seed}_feats"], golden[f"s{seed}_logits"]
+    assert rel(f, ref_f) <= TOL[prec]["out"]
+    assert rel(l, ref_l) <= TOL[prec]["out"]
+    bound = 2 * TOL[prec]["out"] * float(np.abs(ref_l).max())
+    margin = np.abs(ref_l[:, 0] - ref_l[:, 1])
+    decided = margin > bound
+    assert decided.sum() >= 6  # the fixture holds one exact near-tie per seed by construction
+    assert np.array_equal(lab.cpu().numpy()[decided], golden[f"s{seed}_labels"][decided])
+    assert torch.equal(lab, l.argmax(1))  # in-kernel argmax == torch.argmax of our own logits
+    for i, name in enumerate(TAPS):
+        t = net.tap(u8.shape[0], i)[0, :4, :2]
+        ref = torch.from_numpy(golden[f"s{seed}_tap_{name}"])
+        scale = float(golden[f"s{seed}_tap_absmax"][i])
+        assert float((t.cpu() - ref).abs().max()) <= TOL[prec]["tap"] * scale, name
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_full_taps_against_oracle_random_patches(prec):
+    sd = synth.seeded_resnet18_state_dict(2, num_classes=2)
+    u8 = synth.synth_patches_u8(5, seed=11)
+    x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+    taps = {}
+    ref_f, ref_l = R.resnet18_forward(x, sd, taps)
+    net = capi.PackedResNet18(sd, precision=prec)
+    f, l, _ = net.forward(x.cuda(), want_feats=True, want_logits=True)
+    assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
+    for i, name in enumerate(TAPS):
+        assert rel(net.tap(5, i), taps[name]) <= TOL[prec]["tap"], name
+
+
+def test_native_layout_equals_nchw_path_bitwise():
+    sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    u8 = synth.synth_patches_u8(3, seed=4).cuda()
+    net = capi.PackedResNet18(sd, precision="bf16")
+    f1, l1, _ = net.forward(capi.patches_normalize(u8, "nchw_f32"), want_logits=True)
+    f2, l2, _ = net.forward(capi.patches_normalize(u8, "bf16"), want_logits=True, native_layout=True)
+    assert torch.equal(f1, f2) and torch.equal(l1, l2)
+
+
+def test_sub_batching_and_determinism():
+    # 131 patches = one full sub-batch of 128 + a ragged tail of 3
+    sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    net = capi.PackedResNet18(sd, precision="bf16")
+    x = capi.patches_normalize(synth.synth_patches_u8(131, seed=9, device="cuda"), "bf16")
+    f_all, l_all, _ = net.forward(x, want_logits=True, native_layout=True)
+    f_again, _, _ = net.forward(x, native_layout=True)
+    assert torch.equal(f_all, f_again)
+    f_tail, l_tail, _ = net.forward(x[128:].contiguous(), want_logits=True, native_layout=True)
+    assert torch.equal(f_all[128:], f_tail) and torch.equal(l_all[128:], l_tail)
+    f_one, _, _ = net.forward(x[5:6].contiguous(), native_layout=True)
+    assert torch.equal(f_all[5:6], f_one)
+
+
+def test_feature_only_handle_and_error_paths():
+    sd = synth.seeded_resnet18_state_dict(0, num_classes=None)
+    net = capi.PackedResNet18(sd, precision="fp16")
+    assert net.num_classes == 0
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    f, l, _ = net.forward(x)
+    assert f.shape == (2, 512) and l is None
+    with pytest.raises(capi.HipacError):
+        net.forward(x, want_logits=True)
+    with pytest.raises(capi.HipacError):
+        net.forward(x.cpu())
+    with pytest.raises(capi.HipacError):
+        net.forward(torch.randn(2, 3, 200, 200, device="cuda"))
+    f0, _, _ = net.forward(x[:0])
+    assert f0.shape == (0, 512)
+
+
+def test_reference_class_surface_on_gpu():
+    """ResNet18Classifier / ResNet18FeatureExtractor / UnifiedResNet keep the
+    reference's shapes and key layouts and agree with the oracle fed the same weights."""
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import (
+        ResNet18Classifier, ResNet18FeatureExtractor, UnifiedResNet)
+    from ss25_hierarchical_multiscale_image_classification_amd.weights import load_into, to_layout
+
+    bare = synth.seeded_resnet18_state_dict(5, num_classes=2)
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    ref_f, ref_l = R.resnet18_forward(x, bare)
+
+    clf = ResNet18Classifier().set_precision("fp16")
+    rep = load_into(clf, to_layout(bare, "classifier", data_parallel=True))  # a DataParallel checkpoint
+    assert not rep["skipped"]
+    clf = clf.cuda().eval()
+    with torch.no_grad():
+        out = clf(x.cuda())
+    assert out.shape == (3, 2) and rel(out, ref_l) <= TOL["fp16"]["out"]
+    pred, _ = clf.predict(x.cuda())
+    assert pred.dtype == torch.int64 and pred.shape == (3,)
+
+    ext = ResNet18FeatureExtractor(weight_path=None).set_precision("fp16")
+    load_into(ext, to_layout(bare, "classifier"), drop_fc=True)  # the transplant the reference intends (main.py:852-859)
+    ext = ext.cuda().eval()
+    with torch.no_grad():
+        feats = ext(x.cuda())
+    assert feats.shape == (3, 512) and rel(feats, ref_f) <= TOL["fp16"]["out"]
+    assert all(k.startswith("features.") for k in ext.state_dict())
+
+    uni = UnifiedResNet(classifier=False).set_precision("fp16")
+    load_into(uni, to_layout(bare, "simclr"), drop_fc=True)
+    with torch.no_grad():
+        assert rel(uni.cuda().eval()(x.cuda()), ref_f) <= TOL["fp16"]["out"]
+    with pytest.raises(capi.HipacError):
+        uni(x)  # eval-mode CPU tensor: no CPU fallback

@@ -1,0 +1,133 @@
+"""CPU tests of the host layer: loader surface vs the fixture generated from the
+reference's own PatchDataset, key-layout plumbing, grid enumeration, CLI surface."""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import extractor_ref as E
+from ss25_hierarchical_multiscale_image_classification_amd import extract, synth, weights
+from ss25_hierarchical_multiscale_image_classification_amd.main import build_parser, main
+from ss25_hierarchical_multiscale_image_classification_amd.patch_dataset import PatchDataset
+from ss25_hierarchical_multiscale_image_classification_amd.simclr_dataset import SimCLRDataset
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden  # noqa: E402  (only its tree builder; nothing from /root/reference is touched)
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pngtree")
+    make_golden.build_png_tree(str(d))
+    return str(d)
+
+
+def test_patch_dataset_matches_reference_fixture(tree, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "patch_dataset_ref.json")))
+    for name in ("all", "slides", "balanced", "balanced_max3", "max4"):
+        random.seed(123)
+        ds = PatchDataset(tree, verbose=False, **ref[name]["kwargs"])
+        assert len(ds) == ref[name]["n"], name
+        assert {str(k): v for k, v in ds.get_class_counts().items()} == ref[name]["counts"], name
+        mine = {os.path.relpath(p, tree).replace(os.sep, "/"): l for p, l in zip(ds.image_paths, ds.labels)}
+        if name in ("all", "slides"):  # deterministic membership; sampling modes depend on glob order
+            assert mine == ref[name]["path_to_label"], name
+        else:
+            full = ref["all"]["path_to_label"]
+            assert all(full[k] == v for k, v in mine.items())
+    random.seed(123)
+    ds = PatchDataset(tree, transform=lambda im: np.array(im).sum(), verbose=False)
+    img, label, path = ds[0]
+    assert [type(img).__name__, type(label).__name__, type(path).__name__] == ref["item_types"]
+    assert ds.label_map == {"_normal": 0, "_tumor": 1}
+    raw = PatchDataset(tree, raw=True, verbose=False)[0][0]
+    assert raw.dtype == torch.uint8 and raw.shape == (8, 8, 3)
+    two = SimCLRDataset(PatchDataset(tree, verbose=False), transform=lambda im: np.array(im).mean())
+    a, b = two[1]
+    assert a == b and len(two) == 27
+
+
+def test_window_grid_equals_oracle_enumeration():
+    for (w, h) in ((5000, 4200), (224, 224), (225, 1), (1792, 1793), (6250, 6250)):
+        for level in range(4):
+            for stride in (None, E.PATCH_SIZES[level]):
+                P, s, xy = extract.window_grid(w, h, level, stride)
+                P2, s2, _, grid = E.window_grid(w, h, level, stride)
+                assert (P, s) == (P2, s2)
+                assert np.array_equal(xy, np.array([(g[0], g[1]) for g in grid], np.int32).reshape(-1, 2))
+
+
+def test_config3_window_counts_from_survey():
+    # 50 000^2 level 0 -> 224^2 / 112^2 / 56^2 / 28^2 windows at the reference stride
+    dims = [50000, 25000, 12500, 6250]
+    counts = [len(extract.window_grid(d, d, lvl)[2]) for lvl, d in enumerate(dims)]
+    assert counts == [224 * 224, 112 * 112, 56 * 56, 28 * 28] and sum(counts) == 66640
+    assert [len(extract.window_grid(d, d, lvl, stride=extract.PATCH_SIZES[lvl])[2]) for lvl, d in enumerate(dims)] == [784] * 4
+
+
+def test_state_dict_layouts_round_trip():
+    bare = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    for layout in ("classifier", "unified", "simclr", "extractor"):
+        for dp in (False, True):
+            sd = weights.to_layout(bare, layout, data_parallel=dp)
+            assert weights.detect_layout(sd.keys()) == ("classifier" if layout == "unified" else layout)
+            back = weights.canonical_state_dict(sd)
+            expect = {k: v for k, v in bare.items() if not (layout == "extractor" and k.startswith("fc."))}
+            assert back.keys() == expect.keys()
+            assert all(torch.equal(back[k], expect[k]) for k in expect)
+
+
+def test_load_into_maps_prefixes_and_quirk_mode_reproduces_the_noop():
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier, ResNet18FeatureExtractor
+    from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel
+
+    bare = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    donor = weights.to_layout(bare, "classifier")
+    ext = ResNet18FeatureExtractor(weight_path=None)
+    before = ext.state_dict()["features.0.weight"].clone()
+    rep = weights.load_into(ext, donor, drop_fc=True, reference_quirks=True)
+    assert rep["loaded"] == [] and torch.equal(ext.state_dict()["features.0.weight"], before)  # src/main.py:852-859
+    rep = weights.load_into(ext, donor, drop_fc=True)
+    assert len(rep["loaded"]) == 120 and torch.equal(ext.state_dict()["features.0.weight"], bare["conv1.weight"])
+    clf = ResNet18Classifier()
+    assert sorted(k for k in clf.state_dict() if "fc" in k) == ["model.fc.bias", "model.fc.weight"]
+    sim = SimCLRModel()
+    keys = list(sim.state_dict())
+    assert keys[0] == "encoder.conv1.weight" and keys[-4:] == ["projector.0.weight", "projector.0.bias",
+                                                                "projector.2.weight", "projector.2.bias"]
+    assert not any(k.startswith("encoder.fc") for k in keys)
+    # train-mode forward is the ordinary autograd graph (shapes of src/models/simclr.py:26-29)
+    sim.train()
+    assert sim(torch.randn(2, 3, 64, 64)).shape == (2, 128)
+
+
+def test_annotation_xml_and_mask_match_oracle(tmp_path):
+    xml = tmp_path / "tumor_001.xml"
+    xml.write_text("""<?xml version="1.0"?><ASAP_Annotations><Annotations>
+      <Annotation Name="_0" Type="Polygon" PartOfGroup="Tumor"><Coordinates>
+        <Coordinate Order="0" X="100.7" Y="120.2"/><Coordinate Order="1" X="900.9" Y="140.0"/>
+        <Coordinate Order="2" X="700.5" Y="800.4"/></Coordinates></Annotation>
+      <Annotation Name="_1" Type="Polygon"><Coordinates>
+        <Coordinate Order="0" X="1500" Y="1500"/><Coordinate Order="1" X="1600" Y="1500"/>
+        <Coordinate Order="2" X="1600" Y="1650"/><Coordinate Order="3" X="bad" Y="1"/></Coordinates></Annotation>
+      </Annotations></ASAP_Annotations>""")
+    polys = extract.parse_annotation_xml(str(xml))
+    assert len(polys) == 2 and len(polys[1]) == 3 and polys[0][0] == (100.7, 120.2)
+    for dims in ((2000, 1800), (250, 225)):
+        mine = extract.rasterize_mask(polys, dims, (2000, 1800))
+        assert np.array_equal(mine, np.array(E.parse_mask(polys, dims, (2000, 1800))))
+
+
+def test_cli_surface_keeps_reference_flags():
+    p = build_parser()
+    a = p.parse_args(["--patch", "--patch_level", "all", "--extract_features", "--train", "--train_strategy",
+                      "--strategy", "weighted_loss"])
+    assert a.patch and a.extract_features and a.train and a.train_strategy and a.strategy == "weighted_loss"
+    assert p.parse_args([]).patch_level == "3" and p.parse_args([]).strategy == "self_supervised"
+    with pytest.raises(SystemExit):
+        p.parse_args(["--strategy", "nope"])
+    assert main(["--download"]) == 2  # out-of-scope reference flag: refused with a message
