@@ -92,7 +92,7 @@ int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int
                    int last);
 int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
                   int last);
-constexpr int kNumOps = 22;
+constexpr int kNumOps = 21;
 
 // elementwise.hip
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);

@@ -279,7 +279,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     }                            \
   } while (0)
 
-// The trunk is a fixed sequence of 22 launches ("ops"): 0 stem, 1 max-pool, then per
+// The trunk is a fixed sequence of 21 launches ("ops"): 0 stem, 1 max-pool, then per
 // stage conv1(b0) [proj] conv2(b0) conv1(b1) conv2(b1).  `first..last` selects a
 // sub-range (whole trunk by default) so single layers can be timed / profiled.
 struct OpRange {
