@@ -53,26 +53,32 @@ assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 
 
 def per_op_times(net: capi.PackedResNet18, dev, reps: int = 20):
-    """Average launch duration (ms) of every trunk kernel at one sub-batch (128 images),
-    HIP events on torch's current stream == the stream the library launches on."""
-    bc = 128
-    x = torch.randn(bc, 3, 224, 224, device=dev)
+    """Average launch duration (ms) of every trunk kernel, HIP events on torch's current
+    stream == the stream the library launches on.  Early ops (stem..layer2) run on one
+    sub-batch (512 images), late ops (layer3, layer4) on one group (2048 images), exactly
+    as inside hipac_resnet18_forward."""
+    bc = int(os.environ.get("HIPAC_SUBBATCH", "512"))
+    gc = max(int(os.environ.get("HIPAC_GROUP", "2048")), bc)
+    x = torch.randn(gc, 3, 224, 224, device=dev)
     net.forward(x, want_feats=True)  # fills the workspace with real activations
+    del x
     torch.cuda.synchronize()
     out = []
     for i, (name, macs) in enumerate(OPS):
+        n_img = bc if i < 11 else gc
         for _ in range(3):
-            net.run_ops(bc, i, i)
+            net.run_ops(gc, i, i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            net.run_ops(bc, i, i)
+            net.run_ops(gc, i, i)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        out.append({"op": name, "ms": ms, "tflops": (2 * macs * bc / (ms * 1e-3) / 1e12) if macs else None,
-                    "flops_per_launch": 2 * macs * bc})
-    return bc, out
+        out.append({"op": name, "ms": ms, "images": n_img, "us_per_image": ms * 1e3 / n_img,
+                    "tflops": (2 * macs * n_img / (ms * 1e-3) / 1e12) if macs else None,
+                    "flops_per_launch": 2 * macs * n_img})
+    return out
 
 
 def cpu_baseline(n_sample: int = 256):
@@ -148,10 +154,9 @@ def run_resnet(args, rank, world, dev):
         "tflops_whole_path": value * FLOP_PER_PATCH / 1e12 / world,
     }
     if rank == 0:
-        bc, ops = per_op_times(net, dev)
+        ops = per_op_times(net, dev)
         convs = [o for o in ops if o["tflops"]]
-        dom = max(convs, key=lambda o: o["ms"])
-        # the dominant kernel by time; layer1's four 3x3 convs share one instantiation pair
+        dom = max(convs, key=lambda o: o["us_per_image"])  # the kernel that costs most per patch
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
@@ -159,9 +164,9 @@ def run_resnet(args, rank, world, dev):
         rec["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel[{dom['op']}]", "achieved": dom["tflops"],
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_DENSE_TFLOPS,
                            "traffic": traffic, "launch_ms": dom["ms"], "flops_per_launch": dom["flops_per_launch"],
-                           "images_per_launch": bc}
-        rec["per_op"] = [{"op": o["op"], "ms": round(o["ms"], 4), "tflops": None if o["tflops"] is None else round(o["tflops"], 1)}
-                         for o in ops]
+                           "images_per_launch": dom["images"]}
+        rec["per_op"] = [{"op": o["op"], "images": o["images"], "ms": round(o["ms"], 4),
+                          "tflops": None if o["tflops"] is None else round(o["tflops"], 1)} for o in ops]
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
     return rec

@@ -15,14 +15,15 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-OBJ = CSRC / "build"
-LIB = PKG / "libhipac_hip.so"
+OBJ = CSRC / os.environ.get("HIPAC_OBJ_DIR", "build")
+LIB = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")
 SOURCES = ["hipac_capi.hip", "preprocess.hip", "conv_bf16.hip", "conv_f16.hip"]
 HEADERS = ["common.h", "conv_igemm.h", "../../include/hipac.h"]
 ARCH = "gfx950"
 # -ffp-contract=off: the host-side Pillow coefficient restatement must round every
 # double operation separately (no fused multiply-add), see preprocess.hip.
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("HIPAC_EXTRA_FLAGS", "").split()
+FLAGS = [*EXTRA, "-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libhipac_hip.so"
+LIB_PATH = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")  # override: A/B builds of the same ABI
 
 PREC_BF16, PREC_FP16 = 0, 1
 IN_NCHW_F32, IN_NHWC4_PAD = 0, 1

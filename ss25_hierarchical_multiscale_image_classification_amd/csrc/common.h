@@ -72,27 +72,39 @@ struct Net {
   ConvW down[3];
   float* fc_w;  // device float[num_classes][512]
   float* fc_b;
+  char* zero_page;  // device, 256 zero bytes: DMA source for out-of-image conv taps
 };
 
-// Workspace plan for one sub-batch (element type size = 2 bytes).
+// Workspace plan.  The trunk runs in two phases so every launch fills the chip:
+//   early (stem, pool, layer1, layer2: big activations, many tiles) in sub-batches of `bc`
+//   late  (layer3, layer4, head: small maps)                        in groups of `gc` >= bc
+// Offsets are bytes into the caller's workspace; T = 2-byte element.
 struct Plan {
-  int bc;            // images per sub-batch
-  size_t xin;        // T[bc,230,232,4]
-  size_t stem;       // T[bc,112,112,64]
-  size_t pool;       // T[bc,56,56,64]
-  size_t tmp;        // T[bc,56,56,64]   conv1 output of the current block
-  size_t ds;         // T[bc,28,28,128]  projection shortcut of the current block
-  size_t blk[8];     // block outputs (blk[7] is float32)
+  int bc, gc;
+  // early, sized for bc images
+  size_t xin;     // T[bc,230,232,4]
+  size_t stem;    // T[bc,112,112,64]
+  size_t pool;    // T[bc,56,56,64]
+  size_t tmp_e;   // T[bc,56,56,64]   conv1 output of the current early block
+  size_t ds_e;    // T[bc,28,28,128]  projection shortcut (layer2)
+  // late, sized for gc images
+  size_t tmp_l;   // T[gc,14,14,256]
+  size_t ds_l;    // T[gc,14,14,256]
+  // block outputs: blk[0..2] early (bc), blk[3..7] late (gc); blk[7] is float32
+  size_t blk[8];
   size_t total;
 };
 Plan make_plan(int batch);
-
-// per-precision launchers (conv_bf16.hip / conv_f16.hip)
-int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
-                   int last);
-int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
-                  int last);
 constexpr int kNumOps = 21;
+constexpr int kNumEarlyOps = 11;  // stem, pool, layer1 (4), layer2 (5)
+
+// per-precision launchers (conv_bf16.hip / conv_f16.hip): ops first..last of the trunk.
+// Early ops run on `n_early` images (one sub-batch, whose layer2 output lands at image
+// offset `img_off` of the group buffer); late ops on `n_late` images (one group).
+int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                   hipStream_t s, int first, int last);
+int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                  hipStream_t s, int first, int last);
 
 // elementwise.hip
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);

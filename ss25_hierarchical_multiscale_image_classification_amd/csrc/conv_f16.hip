@@ -1,8 +1,8 @@
 // f16 instantiation of the ResNet18 trunk (separate TU so the two precisions compile in parallel).
 #include "conv_igemm.h"
 namespace hipac {
-int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s, int first,
-                   int last) {
-  return run_trunk<_Float16>(net, p, ws, xin, bc, s, first, last);
+int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                   hipStream_t s, int first, int last) {
+  return run_trunk<_Float16>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
 }
 }  // namespace hipac

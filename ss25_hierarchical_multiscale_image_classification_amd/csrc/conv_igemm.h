@@ -217,6 +217,481 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// v2: LDS-DMA ring.  Same GEMM, operand roles and epilogue as above, but the K tiles
+// (one filter tap x 64 input channels: 128-byte rows) are brought in by
+// global_load_lds_dwordx4 (1 KiB = 8 rows per wave-instruction) into an NSTAGE-deep LDS
+// ring that stays NSTAGE-1 tiles ahead of the MFMAs: counted s_waitcnt vmcnt(N), ONE raw
+// s_barrier per K tile, no VGPRs spent on staging.  The LDS image is lane-linear (as the
+// DMA requires), so the bank-conflict swizzle lives on the SOURCE address and on the read:
+// 16-byte chunk c of row R sits at chunk c ^ ((R >> 1) & 7)  (ds_read_b128 conflict-free:
+// within a 16-lane group (R & 1, (R >> 1) & 7) is unique).  Out-of-image taps read a
+// 128-byte zero page.  Workgroup = (BM/64) x (BN/64) waves, each wave 64 pixels x 64
+// channels (2 x 2 MFMA tiles of 32x32, 64 accumulator registers).
+// Grid is 1-D and XCD-aware: the channel tiles of one pixel tile get consecutive slots
+// on ONE XCD (ids congruent mod 8 share an XCD), so the shared A rows hit that XCD's L2.
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
+          bool RELU, bool RESID, bool OUTF32>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
+    const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
+    const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int PAD = KS / 2;
+  constexpr int HO = (HI + 2 * PAD - KS) / STRIDE + 1;
+  constexpr int WO = (WI + 2 * PAD - KS) / STRIDE + 1;
+  constexpr int CC = CIN / 64;
+  constexpr int KT = KS * KS * CC;
+  constexpr int KTOT = KT * 64;
+  constexpr int WM = BM / 64, WN = BN / 64, NWAVES = WM * WN;
+  constexpr int APW = BM / 8 / NWAVES;  // 1-KiB A pieces per wave per K tile
+  constexpr int WPW = BN / 8 / NWAVES;  // 1-KiB W pieces per wave per K tile
+  constexpr int PPW = APW + WPW;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NTILES_N = COUT / BN;
+  static_assert(BM % 64 == 0 && BN % 64 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
+  static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "piece split");
+  static_assert(NSTAGE >= 2 && NSTAGE * STAGE <= 160 * 1024, "LDS ring");
+  static_assert((NSTAGE - 1) * PPW < 64, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  // XCD-aware decode of the 1-D grid
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mt = (slot / NTILES_N) * 8 + xcd;
+  const int nt = slot % NTILES_N;
+  if (mt >= n_mtiles) return;  // uniform per block; grid is padded to a multiple of 8 m-tiles
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- DMA source setup: lane -> (row within piece, destination chunk) -----------------
+  const int prow = lane >> 3;     // row inside the 8-row piece
+  const int dchunk = lane & 7;    // destination 16-byte chunk (lane-linear)
+  int a_off[APW];                 // byte offset of tap (0,0), incl. the swizzled source chunk
+  unsigned a_mask[APW];           // bit (kh*KS+kw): tap inside the image
+#pragma unroll
+  for (int i = 0; i < APW; ++i) {
+    const int row = (wave + NWAVES * i) * 8 + prow;  // row inside the BM tile
+    const int schunk = dchunk ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int b = mm / (HO * WO);
+    const int rem = mm - b * (HO * WO);
+    const int oh = rem / WO, ow = rem - oh * WO;
+    const int ih0 = oh * STRIDE - PAD, iw0 = ow * STRIDE - PAD;
+    a_off[i] = (((b * HI + ih0) * WI + iw0) * CIN + schunk * 8) * 2;
+    unsigned mask = 0;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+        if (ok && (unsigned)(ih0 + kh) < (unsigned)HI && (unsigned)(iw0 + kw) < (unsigned)WI)
+          mask |= 1u << (kh * KS + kw);
+    a_mask[i] = mask;
+  }
+  int w_off[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wave + NWAVES * i) * 8 + prow;  // row inside the BN tile
+    const int schunk = dchunk ^ ((row >> 1) & 7);
+    w_off[i] = ((n0 + row) * KTOT + schunk * 8) * 2;
+  }
+  const char* in_b = reinterpret_cast<const char*>(in);
+  const char* w_b = reinterpret_cast<const char*>(wgt);
+  const char* zsrc = zero_page + dchunk * 16;
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  auto issue = [&](int tap, int tapoff_bytes, int kofs_bytes, int stage) {
+    unsigned char* sbase = ring + stage * STAGE;
+    static_for<APW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const bool ok = (a_mask[i] >> tap) & 1u;
+      const char* src = ok ? in_b + (a_off[i] + tapoff_bytes) : zsrc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave + NWAVES * i) * 1024), 16, 0, 0);
+    });
+    static_for<WPW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_b + (w_off[i] + kofs_bytes)),
+                                       (lptr_t)(sbase + BM * 128 + (wave + NWAVES * i) * 1024), 16, 0, 0);
+    });
+  };
+
+  // ---- fragment read offsets (bytes inside a stage) -------------------------------------
+  const int sw = (r >> 1) & 7;
+  int rd[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) rd[kk] = r * 128 + (((2 * kk + h) ^ sw) << 4);
+  const int a_rd0 = wm * 64 * 128;
+  const int w_rd0 = BM * 128 + wn * 64 * 128;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // issue-side tile counters (tile index ti = (kh*KS + kw)*CC + cc)
+  int i_kh = 0, i_kw = 0, i_cc = 0, i_t = 0;
+  auto issue_next = [&]() {
+    const int tap = i_kh * KS + i_kw;
+    issue(tap, ((i_kh * WI + i_kw) * CIN + i_cc * 64) * 2, i_t * 128, i_t % NSTAGE);
+    ++i_t;
+    if (++i_cc == CC) {
+      i_cc = 0;
+      if (++i_kw == KS) {
+        i_kw = 0;
+        ++i_kh;
+      }
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (p < KT) issue_next();
+
+  for (int t = 0; t < KT; ++t) {
+    // tile t must have landed: tiles t+1 .. min(t+NSTAGE-2, KT-1) may stay in flight
+    const int ahead = (KT - 1 - t) < (NSTAGE - 2) ? (KT - 1 - t) : (NSTAGE - 2);
+    if constexpr (NSTAGE >= 4) {
+      if (ahead >= 2) wait_vmcnt<2 * PPW>();
+      else if (ahead == 1) wait_vmcnt<PPW>();
+      else wait_vmcnt<0>();
+    } else if constexpr (NSTAGE == 3) {
+      if (ahead >= 1) wait_vmcnt<PPW>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are in; stage (t-1)%NSTAGE is free
+    if (t + NSTAGE - 1 < KT) issue_next();
+    const unsigned char* st = ring + (t % NSTAGE) * STAGE;
+    // fragment reads run one k16 step ahead of the MFMAs that consume them
+    frag af[2][2], wf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const frag*>(st + a_rd0 + i * 4096 + rd[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wf[0][j] = *reinterpret_cast<const frag*>(st + w_rd0 + j * 4096 + rd[0]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(st + a_rd0 + i * 4096 + rd[kk + 1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(st + w_rd0 + j * 4096 + rd[kk + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // the reads of this stage must have retired before any wave passes the next barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- epilogue: +bias (+residual) (ReLU) -> NHWC store ---------------------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + r;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        float v0 = acc[i][j][4 * q + 0] + bv.x;
+        float v1 = acc[i][j][4 * q + 1] + bv.y;
+        float v2 = acc[i][j][4 * q + 2] + bv.z;
+        float v3 = acc[i][j][4 * q + 3] + bv.w;
+        const size_t o = (size_t)m * COUT + c0;
+        if constexpr (RESID) {
+          const typename E::vec4 rv = *reinterpret_cast<const typename E::vec4*>(resid + o);
+          v0 += (float)rv[0];
+          v1 += (float)rv[1];
+          v2 += (float)rv[2];
+          v3 += (float)rv[3];
+        }
+        if constexpr (RELU) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+          v2 = fmaxf(v2, 0.f);
+          v3 = fmaxf(v3, 0.f);
+        }
+        if constexpr (OUTF32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + o) = make_float4(v0, v1, v2, v3);
+        } else {
+          typename E::vec4 ov;
+          ov[0] = (T)v0;
+          ov[1] = (T)v1;
+          ov[2] = (T)v2;
+          ov[3] = (T)v3;
+          *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp) + o) = ov;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// v3: halo direct convolution for the 3x3 / stride 1 / pad 1 layers (13 of the 20 convs,
+// 83 % of the FLOPs).  The v2 kernel re-stages the activation tile once per filter tap
+// (9x the input through L2 -> LDS, which is what bounds it at ~11 TB/s); here a workgroup
+// brings the input rows its BM output pixels need -- a band of zero-padded rows, 64
+// channels deep -- into LDS ONCE per 64-channel chunk and all 9 taps read it at shifted
+// pixel offsets.  Only the weight tile (BN x 64 channels per tap) still streams, through a
+// 2-slot LDS-DMA ring one tap ahead of the MFMAs.
+//
+// Geometry: output pixels are flattened m = (b*H + y)*W + x; in zero-padded coordinates
+// (rows 0..H+1 per image, cols 0..W+1) tap (kh,kw) of pixel (b,y,x) reads padded row
+// b*(H+2) + y + kh, col x + kw.  The band a workgroup needs is the contiguous range of
+// padded rows [Rp(first pixel), Rp(last pixel) + 2] (it may cross image boundaries: the
+// bottom/top pad rows of neighbouring images are just zero rows in the band).  In LDS the
+// band is [pixel q = row*(W+2) + col][64 ch] with the same chunk swizzle as v2
+// (c ^ ((q >> 1) & 7)); a lane's read address for a tap is q0 + kh*(W+2) + kw.
+// ---------------------------------------------------------------------------------------
+template <int H, int W, int BM>
+constexpr int halo_rows_max() {
+  int best = 0;
+  for (int k = 0; k < 2 * H * W; ++k) {
+    const long long m0 = (long long)k * BM, m1 = m0 + BM - 1;
+    const int r0 = (int)((m0 / (H * W)) * (H + 2) + (m0 % (H * W)) / W);
+    const int r1 = (int)((m1 / (H * W)) * (H + 2) + (m1 % (H * W)) / W) + 2;
+    if (r1 - r0 + 1 > best) best = r1 - r0 + 1;
+  }
+  return best;
+}
+
+template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, bool RELU, bool RESID, bool OUTF32>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                           const float* __restrict__ bias,
+                                                           const T* __restrict__ resid, void* __restrict__ outp,
+                                                           int M, int n_img, int n_mtiles,
+                                                           const char* __restrict__ zero_page) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int CC = CIN / 64;
+  constexpr int KTOT = 9 * CIN;
+  constexpr int WP = W + 2, HPAD = H + 2;
+  constexpr int WM = BM / 64, WN = 4 / WM;          // 4 waves: WM x WN
+  constexpr int WTN = BN / WN, NT = WTN / 32;       // channels per wave, 32-wide tiles per wave
+  constexpr int ROWS_MAX = halo_rows_max<H, W, BM>();
+  constexpr int A_PIECES = (ROWS_MAX * WP + 7) / 8;
+  constexpr int A_BYTES = A_PIECES * 1024;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
+  constexpr int NTILES_N = COUT / BN;
+  static_assert(BM % 64 == 0 && WM * WN == 4 && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
+  static_assert((BN / 8) % 4 == 0, "W piece split");
+  static_assert(A_BYTES + 2 * W_BYTES <= 160 * 1024, "LDS");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  unsigned char* const Abuf = ring;
+  unsigned char* const Wbuf = ring + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mt = (slot / NTILES_N) * 8 + xcd;
+  const int nt = slot % NTILES_N;
+  if (mt >= n_mtiles) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // band of padded rows needed by pixels m0 .. min(m0+BM, M)-1
+  const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
+  const int b_first = m0 / (H * W), b_last = mlast / (H * W);
+  const int rp_lo = b_first * HPAD + (m0 - b_first * (H * W)) / W;
+  const int rp_hi = b_last * HPAD + (mlast - b_last * (H * W)) / W + 2;
+  const int npx = (rp_hi - rp_lo + 1) * WP;      // <= ROWS_MAX * WP by construction
+  const int npieces = (npx + 7) >> 3;
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const char* in_b = reinterpret_cast<const char*>(in);
+  const char* w_b = reinterpret_cast<const char*>(wgt);
+  const int prow = lane >> 3, dchunk = lane & 7;
+
+  // DMA of the band for channel chunk cc (all 4 waves, piece p -> wave p % 4)
+  auto issue_band = [&](int cc) {
+    for (int p = wave; p < npieces; p += 4) {
+      const int q = p * 8 + prow;
+      const int rr = q / WP, cx = q - rr * WP;
+      const int rp = rp_lo + rr;
+      const int b = rp / HPAD, py = rp - b * HPAD;
+      const int y = py - 1, x = cx - 1;
+      const bool ok = q < npx && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && b < n_img;
+      const int schunk = dchunk ^ ((q >> 1) & 7);
+      const char* src = ok ? in_b + ((((size_t)b * H + y) * W + x) * CIN + cc * 64 + schunk * 8) * 2
+                           : zero_page + dchunk * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
+    }
+  };
+  int w_off[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    w_off[i] = ((n0 + row) * KTOT + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
+  }
+  auto issue_w = [&](int kofs_bytes, int slot_) {
+    static_for<WPW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_b + (w_off[i] + kofs_bytes)),
+                                       (lptr_t)(Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+    });
+  };
+
+  // ---- consumer side: band pixel of this lane's two output pixels (tap 0,0) -------------
+  int q0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + wm * 64 + i * 32 + r;
+    m = m <= mlast ? m : mlast;  // tail lanes read a valid pixel; their results are not stored
+    const int b = m / (H * W);
+    const int rem = m - b * (H * W);
+    const int y = rem / W, x = rem - y * W;
+    q0[i] = (b * HPAD + y - rp_lo) * WP + x;
+  }
+  const int sw_w = (r >> 1) & 7;
+  int rdw[4], ck[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    ck[kk] = (2 * kk + h) << 4;
+    rdw[kk] = (wn * WTN + r) * 128 + (((2 * kk + h) ^ sw_w) << 4);
+  }
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // step s = cc*9 + tap; the weights' K offset of step s is ((tap)*CIN + cc*64) elements
+  auto kofs = [&](int cc, int tap) { return (tap * CIN + cc * 64) * 2; };
+
+  issue_band(0);
+  issue_w(kofs(0, 0), 0);
+  int s = 0;
+  for (int cc = 0; cc < CC; ++cc) {
+    if (cc > 0) {
+      // every wave has finished reading the previous chunk's band (lgkmcnt(0) below + this barrier)
+      __builtin_amdgcn_s_barrier();
+      issue_band(cc);
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++s) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // band (tap 0) and W(s) landed for every wave; W slot (s+1)&1 is free
+      {
+        const int ntap = tap + 1 == 9 ? 0 : tap + 1;
+        const int ncc = tap + 1 == 9 ? cc + 1 : cc;
+        if (ncc < CC) issue_w(kofs(ncc, ntap), (s + 1) & 1);
+      }
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int toff = kh * WP + kw;
+      const unsigned char* wst = Wbuf + (s & 1) * W_BYTES;
+      int abase[2], asw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = q0[i] + toff;
+        abase[i] = q << 7;
+        asw[i] = ((q >> 1) & 7) << 4;
+      }
+      frag af[2][2], wf[2][NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[0] ^ asw[i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[0][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[0]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[kk + 1] ^ asw[i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[kk + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  // ---- epilogue: +bias (+residual) (ReLU) -> NHWC store ---------------------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + r;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = n0 + wn * WTN + j * 32 + 8 * q + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        float v0 = acc[i][j][4 * q + 0] + bv.x;
+        float v1 = acc[i][j][4 * q + 1] + bv.y;
+        float v2 = acc[i][j][4 * q + 2] + bv.z;
+        float v3 = acc[i][j][4 * q + 3] + bv.w;
+        const size_t o = (size_t)m * COUT + c0;
+        if constexpr (RESID) {
+          const typename E::vec4 rv = *reinterpret_cast<const typename E::vec4*>(resid + o);
+          v0 += (float)rv[0];
+          v1 += (float)rv[1];
+          v2 += (float)rv[2];
+          v3 += (float)rv[3];
+        }
+        if constexpr (RELU) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+          v2 = fmaxf(v2, 0.f);
+          v3 = fmaxf(v3, 0.f);
+        }
+        if constexpr (OUTF32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + o) = make_float4(v0, v1, v2, v3);
+        } else {
+          typename E::vec4 ov;
+          ov[0] = (T)v0;
+          ov[1] = (T)v1;
+          ov[2] = (T)v2;
+          ov[3] = (T)v3;
+          *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp) + o) = ov;
+        }
+      }
+    }
+  }
+}
+
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
 // post-ReLU (>= 0) so the implicit -inf padding never wins; out-of-range taps
 // are simply skipped.
@@ -256,17 +731,73 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
   *reinterpret_cast<frag*>(out + (((size_t)b * HO + oh) * WO + ow) * C + c8 * 8) = o;
 }
 
+#ifndef HIPAC_USE_HALO
+#define HIPAC_USE_HALO 1
+#endif
+#ifndef HIPAC_BM_A
+#define HIPAC_BM_A 128
+#endif
+#ifndef HIPAC_NSTAGE_A
+#define HIPAC_NSTAGE_A 2
+#endif
+#ifndef HIPAC_NSTAGE_B
+#define HIPAC_NSTAGE_B 2
+#endif
+#ifndef HIPAC_BM_64
+#define HIPAC_BM_64 256
+#endif
+// Tile shape per layer: COUT = 64 -> 256 pixels x 64 channels (4 waves);
+// otherwise 128 x 128 (4 waves, 4-stage ring).
+template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = 128, NSTAGE = HIPAC_NSTAGE_A; };
+template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
+
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, bool RELU, bool RESID,
           bool OUTF32, bool STEM = false>
-static int launch_conv(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s) {
-  constexpr int BN = COUT >= 128 ? 128 : 64;
+static int launch_conv(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s,
+                       const char* zero_page = nullptr) {
   constexpr int PAD = STEM ? 0 : KS / 2;
   constexpr int HO = STEM ? 112 : (HI + 2 * PAD - KS) / STRIDE + 1;
   constexpr int WO = STEM ? 112 : (WI + 2 * PAD - KS) / STRIDE + 1;
   const int M = n * HO * WO;
-  dim3 grid((M + 127) / 128, COUT / BN);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
-                     grid, dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M);
+  if constexpr (STEM) {
+    constexpr int BN = 64;
+    dim3 grid((M + 127) / 128, COUT / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
+                       grid, dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M);
+  } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
+    constexpr int BM = 128, BN = COUT >= 128 ? 128 : 64;
+    constexpr int A_BYTES = ((halo_rows_max<HI, WI, BM>() * (WI + 2) + 7) / 8) * 1024;
+    constexpr int LDS = A_BYTES + 2 * BN * 128;
+    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, RELU, RESID, OUTF32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    const int n_mtiles = (M + BM - 1) / BM;
+    const int mt8 = (n_mtiles + 7) / 8 * 8;
+    dim3 grid(mt8 * (COUT / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
+                       n_mtiles, zero_page);
+  } else {
+    using C = TileCfg<COUT>;
+    constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
+    constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
+    constexpr int LDS = NSTAGE * (BM + BN) * 128;
+    auto kern = conv_glds_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BM, BN, NSTAGE, RELU, RESID, OUTF32>;
+    static bool attr_done = false;  // idempotent; a benign race at worst repeats the call
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    const int n_mtiles = (M + BM - 1) / BM;
+    const int mt8 = (n_mtiles + 7) / 8 * 8;
+    dim3 grid(mt8 * (COUT / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out,
+                       M, n_mtiles, zero_page);
+  }
   return (int)hipGetLastError();
 }
 
@@ -293,52 +824,46 @@ struct OpRange {
 // One ResNet stage = two BasicBlocks.  CI/HI: input channels / spatial size,
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
 template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST>
-static int run_stage(const Net& net, int stage, const void* x, char* ws, const Plan& p, int bc, hipStream_t s,
-                     OpRange& ops) {
+static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
+                     hipStream_t s, OpRange& ops) {
   constexpr int HO = HI / STRIDE;
-  void* tmp = ws + p.tmp;
-  void* ds = ws + p.ds;
-  void* o0 = ws + p.blk[2 * stage];
-  void* o1 = ws + p.blk[2 * stage + 1];
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
+  const char* z = net.zero_page;
   // block 0
-  if (ops.take())
-    HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, bc, s)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, n, s, z)));
   const void* idt = x;
   if constexpr (STRIDE != 1 || CI != CO) {
     if (ops.take())
-      HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr,
-                                                                               ds, bc, s)));
+      HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
     idt = ds;
   }
-  if (ops.take())
-    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, bc, s)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, n, s, z)));
   // block 1
-  if (ops.take())
-    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false>(o0, bw1[0], nullptr, tmp, bc, s)));
-  if (ops.take())
-    HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST>(tmp, bw1[1], o0, o1, bc, s)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false>(o0, bw1[0], nullptr, tmp, n, s, z)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST>(tmp, bw1[1], o0, o1, n, s, z)));
   return 0;
 }
 
 template <typename T>
-static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int bc, hipStream_t s,
-                     int first, int last) {
+static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                     hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
+  const int ne = n_early, nl = n_late;
   if (ops.take())
-    HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr,
-                                                                               ws + p.stem, bc, s)));
+    HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
   if (ops.take()) {
-    const long long total = (long long)bc * 56 * 56 * 8;
+    const long long total = (long long)ne * 56 * 56 * 8;
     hipLaunchKernelGGL((maxpool3x3s2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       (const T*)(ws + p.stem), (T*)(ws + p.pool), bc);
+                       (const T*)(ws + p.stem), (T*)(ws + p.pool), ne);
     HIPAC_TRY((int)hipGetLastError());
   }
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws, p, bc, s, ops)));
-  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws, p, bc, s, ops)));
-  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws, p, bc, s, ops)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws, p, bc, s, ops)));
+  // layer2's second block writes straight into this sub-batch's slice of the group buffer
+  char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * sizeof(T);
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops)));
+  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
+  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops)));
   return 0;
 }
 

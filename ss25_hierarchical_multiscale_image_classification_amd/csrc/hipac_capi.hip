@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -38,13 +39,28 @@ static inline uint16_t to_bits(float f, int precision) {
   return precision == HIPAC_PREC_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
 }
 
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  if (const char* e = getenv(name)) {
+    const int v = atoi(e);
+    if (v >= lo && v <= hi) return v;
+  }
+  return dflt;
+}
+
 Plan make_plan(int batch) {
   Plan p;
-  // Sub-batch: large enough to fill 256 CUs in layer4 (49 pixels/image), small
-  // enough that one sub-batch's activations stay inside the 256 MiB Infinity Cache.
-  p.bc = batch < 128 ? batch : 128;
-  if (p.bc < 1) p.bc = 1;
-  const size_t b = (size_t)p.bc;
+  // bc: early sub-batch -- 512 images give layer1/2 thousands of tiles (block-round
+  // quantisation < 10 %).  gc: late group -- layer4 has only 49 pixels per image, so it
+  // needs ~2048 images to fill 256 CUs x 2 workgroups for several rounds.
+  // (tuning knobs; a whole run must use one setting)
+  const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
+  const int gc_cap = env_int("HIPAC_GROUP", 2048, 1, 4096);
+  if (batch < 1) batch = 1;
+  p.bc = batch < bc_cap ? batch : bc_cap;
+  p.gc = batch < gc_cap ? batch : gc_cap;
+  if (p.gc < p.bc) p.gc = p.bc;
+  p.gc = (p.gc + p.bc - 1) / p.bc * p.bc;  // whole sub-batches per group
+  const size_t b = (size_t)p.bc, g = (size_t)p.gc;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -54,15 +70,18 @@ Plan make_plan(int batch) {
   p.xin = take(b * kPadH * kPadW * 4 * 2);
   p.stem = take(b * 112 * 112 * 64 * 2);
   p.pool = take(b * 56 * 56 * 64 * 2);
-  p.tmp = take(b * 56 * 56 * 64 * 2);
-  p.ds = take(b * 28 * 28 * 128 * 2);
-  const int hw[4] = {56, 28, 14, 7};
-  const int ch[4] = {64, 128, 256, 512};
-  for (int s = 0; s < 4; ++s)
-    for (int k = 0; k < 2; ++k) {
-      const size_t esz = (s == 3 && k == 1) ? 4 : 2;
-      p.blk[2 * s + k] = take(b * hw[s] * hw[s] * ch[s] * esz);
-    }
+  p.tmp_e = take(b * 56 * 56 * 64 * 2);
+  p.ds_e = take(b * 28 * 28 * 128 * 2);
+  p.blk[0] = take(b * 56 * 56 * 64 * 2);
+  p.blk[1] = take(b * 56 * 56 * 64 * 2);
+  p.blk[2] = take(b * 28 * 28 * 128 * 2);
+  p.blk[3] = take(g * 28 * 28 * 128 * 2);
+  p.tmp_l = take(g * 14 * 14 * 256 * 2);
+  p.ds_l = take(g * 14 * 14 * 256 * 2);
+  p.blk[4] = take(g * 14 * 14 * 256 * 2);
+  p.blk[5] = take(g * 14 * 14 * 256 * 2);
+  p.blk[6] = take(g * 7 * 7 * 512 * 2);
+  p.blk[7] = take(g * 7 * 7 * 512 * 4);
   p.total = off;
   return p;
 }
@@ -249,6 +268,7 @@ void hipac_weights_free(hipac_weights_t* w) {
   for (int i = 0; i < 3; ++i) free_convw(w->net.down[i]);
   if (w->net.fc_w) (void)hipFree(w->net.fc_w);
   if (w->net.fc_b) (void)hipFree(w->net.fc_b);
+  if (w->net.zero_page) (void)hipFree(w->net.zero_page);
   delete w;
 }
 
@@ -274,6 +294,10 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     if (!rc) rc = pack_conv(params->block[2 * s + 1][0], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][0]);
     if (!rc) rc = pack_conv(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0) rc = pack_conv(params->down[s - 1], ch[s], cin, 1, eps, precision, false, &w->net.down[s - 1]);
+  }
+  if (!rc) {
+    const char zeros[256] = {0};
+    rc = upload(zeros, sizeof(zeros), (void**)&w->net.zero_page);
   }
   if (!rc && params->num_classes > 0) {
     HIPAC_REQUIRE(params->fc_b != nullptr, HIPAC_EINVAL, "pack: fc_b is null");
@@ -314,23 +338,27 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   char* ws = (char*)workspace;
   const Net& net = w->net;
   const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * 2;
-  for (int b0 = 0; b0 < batch; b0 += p.bc) {
-    const int bc = batch - b0 < p.bc ? batch - b0 : p.bc;
-    const void* xin = ws + p.xin;
-    if (in_layout == HIPAC_IN_NCHW_F32) {
-      int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)b0 * 3 * kPatch * kPatch, ws + p.xin, bc,
-                                    net.precision, s);
-      HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
-    } else {
-      // native layout: run the stem straight off the caller's buffer
-      xin = (const char*)x + (size_t)b0 * in_img_bytes;
+  auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+  for (int g0 = 0; g0 < batch; g0 += p.gc) {
+    const int gn = batch - g0 < p.gc ? batch - g0 : p.gc;
+    for (int b0 = 0; b0 < gn; b0 += p.bc) {
+      const int bn = gn - b0 < p.bc ? gn - b0 : p.bc;
+      const void* xin = ws + p.xin;
+      if (in_layout == HIPAC_IN_NCHW_F32) {
+        int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
+                                      net.precision, s);
+        HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
+      } else {
+        xin = (const char*)x + (size_t)(g0 + b0) * in_img_bytes;  // native layout: stem reads the caller's buffer
+      }
+      int rc = trunk(net, p, ws, xin, bn, b0, 0, s, 0, kNumEarlyOps - 1);
+      if (rc) return rc;
     }
-    int rc = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16(net, p, ws, xin, bc, s, 0, kNumOps)
-                                               : run_trunk_f16(net, p, ws, xin, bc, s, 0, kNumOps);
+    int rc = trunk(net, p, ws, nullptr, 0, 0, gn, s, kNumEarlyOps, kNumOps - 1);
     if (rc) return rc;
-    rc = launch_head((const float*)(ws + p.blk[7]), bc, net.fc_w, net.fc_b, net.num_classes,
-                     feats ? feats + (size_t)b0 * 512 : nullptr,
-                     logits ? logits + (size_t)b0 * net.num_classes : nullptr, labels ? labels + b0 : nullptr, s);
+    rc = launch_head((const float*)(ws + p.blk[7]), gn, net.fc_w, net.fc_b, net.num_classes,
+                     feats ? feats + (size_t)g0 * 512 : nullptr,
+                     logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s);
     HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
   }
   return 0;
@@ -340,15 +368,16 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, void* workspace, size_t wor
                            int first_op, int last_op, void* stream) {
   HIPAC_REQUIRE(w && workspace, HIPAC_EINVAL, "run_ops: null argument");
   const Plan p = make_plan(batch);
-  HIPAC_REQUIRE(batch > 0 && batch <= p.bc, HIPAC_EINVAL, "run_ops: batch %d exceeds one sub-batch (%d)", batch, p.bc);
+  HIPAC_REQUIRE(batch > 0 && batch <= p.gc, HIPAC_EINVAL, "run_ops: batch %d exceeds one group (%d)", batch, p.gc);
   HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "run_ops: workspace %zu < required %zu",
                 workspace_bytes, p.total);
   HIPAC_REQUIRE(first_op >= 0 && first_op <= last_op && last_op < kNumOps, HIPAC_EINVAL, "run_ops: range %d..%d",
                 first_op, last_op);
   char* ws = (char*)workspace;
-  return w->net.precision == HIPAC_PREC_BF16
-             ? run_trunk_bf16(w->net, p, ws, ws + p.xin, batch, (hipStream_t)stream, first_op, last_op)
-             : run_trunk_f16(w->net, p, ws, ws + p.xin, batch, (hipStream_t)stream, first_op, last_op);
+  auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+  // early ops act on the first sub-batch, late ops on the whole group
+  const int ne = batch < p.bc ? batch : p.bc;
+  return trunk(w->net, p, ws, ws + p.xin, ne, 0, batch, (hipStream_t)stream, first_op, last_op);
 }
 
 int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap, float* dst,

@@ -86,16 +86,23 @@ def test_native_layout_equals_nchw_path_bitwise():
     assert torch.equal(f1, f2) and torch.equal(l1, l2)
 
 
-def test_sub_batching_and_determinism():
-    # 131 patches = one full sub-batch of 128 + a ragged tail of 3
+def test_sub_batching_and_determinism(monkeypatch):
+    # internal schedule: early layers in sub-batches, late layers in groups.  Shrink both so
+    # 131 patches = group 96 (sub-batches 48 + 48) + ragged group 35.
+    monkeypatch.setenv("HIPAC_SUBBATCH", "48")
+    monkeypatch.setenv("HIPAC_GROUP", "96")
     sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
     net = capi.PackedResNet18(sd, precision="bf16")
     x = capi.patches_normalize(synth.synth_patches_u8(131, seed=9, device="cuda"), "bf16")
     f_all, l_all, _ = net.forward(x, want_logits=True, native_layout=True)
     f_again, _, _ = net.forward(x, native_layout=True)
     assert torch.equal(f_all, f_again)
-    f_tail, l_tail, _ = net.forward(x[128:].contiguous(), want_logits=True, native_layout=True)
-    assert torch.equal(f_all[128:], f_tail) and torch.equal(l_all[128:], l_tail)
+    f_tail, l_tail, _ = net.forward(x[96:].contiguous(), want_logits=True, native_layout=True)
+    assert torch.equal(f_all[96:], f_tail) and torch.equal(l_all[96:], l_tail)
+    monkeypatch.delenv("HIPAC_SUBBATCH")
+    monkeypatch.delenv("HIPAC_GROUP")
+    f_big, _, _ = capi.PackedResNet18(sd, precision="bf16").forward(x, native_layout=True)  # default schedule
+    assert torch.equal(f_all, f_big)
     f_one, _, _ = net.forward(x[5:6].contiguous(), native_layout=True)
     assert torch.equal(f_all[5:6], f_one)
 
