@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 // Element traits: the MFMA operand types for the two supported precisions.
 template <typename T> struct Elem;
@@ -81,6 +82,7 @@ struct Net {
 // Offsets are bytes into the caller's workspace; T = 2-byte element.
 struct Plan {
   int bc, gc;
+  int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]
   size_t stem;    // T[bc,112,112,64]

@@ -692,6 +692,175 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused stem: 7x7/2 conv (+BN+ReLU) and the 3x3/2 max-pool in one kernel, so the
+// 112x112x64 stem activation (1.6 MB per patch, the largest tensor of the network) never
+// reaches HBM.  A workgroup (4 waves) produces an 8x7 tile of POOLED pixels: it needs the
+// 17x15 = 255 stem pixels around it (exactly 8 MFMA sub-tiles of 32), which need a 39x36
+// pixel patch of the padded NHWC4 input (11 KB).  Workgroups are persistent (grid-stride
+// over tiles) and every lane keeps ITS slice of the whole stem weight matrix in registers
+// (2 channel tiles x 7 kh x 2 k16 fragments = 112 VGPRs): weights are fetched once per
+// workgroup and never re-read, so LDS serves only the activation fragments (1 read per 2
+// MFMAs).  The input patch is double-buffered with a register prefetch of the next tile
+// behind the MFMAs; the stem tile goes to LDS (bias, ReLU, rounded to T exactly as the
+// unfused path stores it) and each thread reduces pooled pixels x 8 channels.
+// Stem pixels outside the image (row/col -1) are stored as 0: inputs are post-ReLU (>= 0),
+// so they can never win the max.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__ xin, const T* __restrict__ wgt,
+                                                        const float* __restrict__ bias, T* __restrict__ out,
+                                                        int n_tiles) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int PTH = 8, PTW = 7;                                       // pooled tile
+  constexpr int STW = 2 * PTW + 1, STH = 2 * PTH + 1, NPX = STW * STH;  // 15 x 17 = 255 stem pixels
+  constexpr int PROWS = 2 * STH + 5, PCOLS = 36;                        // 39 x 36 input pixels (8 B each)
+  constexpr int PPR = PCOLS / 2;                                        // 16-byte pieces per patch row
+  constexpr int NPIECE = PROWS * PPR;                                   // 702
+  constexpr int PF = (NPIECE + 255) / 256;                              // pieces per thread (3)
+  constexpr int TILES_X = 56 / PTW, TILES_Y = 56 / PTH, TPI = TILES_X * TILES_Y;  // 8 x 7 = 56 per image
+  constexpr int SPX = 144;  // stem-tile pixel stride in LDS: 128 B of channels + 16 B pad (bank spread)
+  constexpr int P_BYTES = PROWS * PCOLS * 8, S_BYTES = 256 * SPX;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + S_BYTES];
+  unsigned char* const Sl = smem + 2 * P_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // this lane's rows of the weight matrix, all of K, in registers for the kernel's lifetime
+  frag wreg[2][7][2];
+  {
+    const char* wb = reinterpret_cast<const char*>(wgt) + r * 448 + 16 * h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          wreg[j][kh][kk] = *reinterpret_cast<const frag*>(wb + j * 32 * 448 + kh * 64 + kk * 32);
+  }
+  float4 bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(bias + j * 32 + 8 * q + 4 * h);
+
+  // the two stem pixels of this lane (sub-tiles 2*wave, 2*wave+1); pixel 255 does not exist
+  int P[2], a_rd[2], ly[2], lx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    P[i] = (2 * wave + i) * 32 + r;
+    const int Pc = P[i] < NPX ? P[i] : NPX - 1;
+    ly[i] = Pc / STW;
+    lx[i] = Pc - ly[i] * STW;
+    a_rd[i] = ((2 * ly[i]) * PCOLS + 2 * lx[i]) * 8 + 16 * h;
+  }
+
+  auto tile_origin = [&](int tile, int& b, int& py0, int& px0) {
+    b = tile / TPI;
+    const int t = tile - b * TPI;
+    const int ty = t / TILES_X;
+    py0 = ty * PTH;
+    px0 = (t - ty * TILES_X) * PTW;
+  };
+  u32x4 pre[PF];
+  auto fetch = [&](int tile) {  // global -> registers: the input patch of `tile`
+    int b, py0, px0;
+    tile_origin(tile, b, py0, px0);
+    const int R0 = 2 * (2 * py0 - 1), C0 = 2 * (2 * px0 - 1);
+    const char* img = reinterpret_cast<const char*>(xin) + (size_t)b * kPadH * kPadW * 8;
+    static_for<PF>([&](auto I) {
+      constexpr int k = decltype(I)::value;
+      const int i = tid + 256 * k;
+      const int row = i / PPR, cp = i - row * PPR;
+      const int R = R0 + row, C = C0 + 2 * cp;
+      const bool ok = i < NPIECE && R >= 0 && C >= 0;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + (ok ? ((size_t)R * kPadW + C) * 8 : 0));
+      pre[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    });
+  };
+  auto stash = [&](int buf) {  // registers -> LDS patch buffer
+    static_for<PF>([&](auto I) {
+      constexpr int k = decltype(I)::value;
+      const int i = tid + 256 * k;
+      if (i < NPIECE) *reinterpret_cast<u32x4*>(smem + buf * P_BYTES + i * 16) = pre[k];
+    });
+  };
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) {
+    fetch(tile);
+    stash(0);
+  }
+  __syncthreads();
+  for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    const bool more = tile + (int)gridDim.x < n_tiles;
+    if (more) fetch(tile + gridDim.x);  // in flight behind the MFMAs
+    int b, py0, px0;
+    tile_origin(tile, b, py0, px0);
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const unsigned char* Pl = smem + buf * P_BYTES;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        frag af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const frag*>(Pl + a_rd[i] + kh * (PCOLS * 8) + kk * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma(wreg[j][kh][kk], af[i], acc[i][j]);
+      }
+    }
+    // bias + ReLU -> LDS stem tile [pixel][64 ch]; out-of-image stem pixels become 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool inside = (sy0 + ly[i]) >= 0 && (sx0 + lx[i]) >= 0 && P[i] < NPX;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          typename E::vec4 ov;
+          ov[0] = (T)(inside ? fmaxf(acc[i][j][4 * q + 0] + bv[j][q].x, 0.f) : 0.f);
+          ov[1] = (T)(inside ? fmaxf(acc[i][j][4 * q + 1] + bv[j][q].y, 0.f) : 0.f);
+          ov[2] = (T)(inside ? fmaxf(acc[i][j][4 * q + 2] + bv[j][q].z, 0.f) : 0.f);
+          ov[3] = (T)(inside ? fmaxf(acc[i][j][4 * q + 3] + bv[j][q].w, 0.f) : 0.f);
+          *reinterpret_cast<typename E::vec4*>(Sl + P[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = ov;
+        }
+    }
+    __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]... (see below)
+    if (more) stash(buf ^ 1);  // patch[buf^1] was last read by the MFMAs of the previous iteration
+    // 3x3/2 max-pool of the tile: pooled pixel x 8 channels per thread item
+    for (int item = tid; item < PTH * PTW * 8; item += 256) {
+      const int pp = item >> 3, c8 = item & 7;
+      const int py = pp / PTW, px = pp - py * PTW;
+      // values are post-ReLU (sign bit clear, or -0.0): their 16-bit patterns order like
+      // signed integers, so the max is a packed integer max -- no conversions
+      s16x8 best = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          best = __builtin_elementwise_max(
+              best, *reinterpret_cast<const s16x8*>(Sl + ((2 * py + dy) * STW + 2 * px + dx) * SPX + c8 * 16));
+      const frag o = __builtin_bit_cast(frag, best);
+      *reinterpret_cast<frag*>(out + (((size_t)b * 56 + py0 + py) * 56 + px0 + px) * 64 + c8 * 8) = o;
+    }
+    __syncthreads();  // pooling reads done (stem tile free) and patch[buf ^ 1] visible
+  }
+}
+
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
 // post-ReLU (>= 0) so the implicit -inf padding never wins; out-of-range taps
 // are simply skipped.
@@ -850,6 +1019,17 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
                      hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
   const int ne = n_early, nl = n_late;
+  if (p.fuse_stem) {
+    // op 0 = fused stem + max-pool (the 112x112 stem map is never materialised), op 1 = nothing
+    if (ops.take()) {
+      const int n_tiles = ne * 56;
+      const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent: 2 workgroups per CU
+      hipLaunchKernelGGL((stem_pool_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)xin, (const T*)net.stem.w,
+                         net.stem.bias, (T*)(ws + p.pool), n_tiles);
+      HIPAC_TRY((int)hipGetLastError());
+    }
+    (void)ops.take();
+  } else {
   if (ops.take())
     HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
   if (ops.take()) {
@@ -857,6 +1037,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     hipLaunchKernelGGL((maxpool3x3s2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        (const T*)(ws + p.stem), (T*)(ws + p.pool), ne);
     HIPAC_TRY((int)hipGetLastError());
+  }
   }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
   char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * sizeof(T);

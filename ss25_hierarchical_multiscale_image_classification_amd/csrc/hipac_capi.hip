@@ -55,6 +55,7 @@ Plan make_plan(int batch) {
   // (tuning knobs; a whole run must use one setting)
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
   const int gc_cap = env_int("HIPAC_GROUP", 2048, 1, 4096);
+  p.fuse_stem = env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -390,6 +391,8 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
   const void* src;
   int C, H, is_f32 = 0;
   if (tap == 0) {
+    HIPAC_REQUIRE(!p.fuse_stem, HIPAC_EUNSUPPORTED,
+                  "tap 0 (stem) does not exist when the stem is fused with the max-pool; set HIPAC_FUSE_STEM=0");
     src = ws + p.stem, C = 64, H = 112;
   } else if (tap == 1) {
     src = ws + p.pool, C = 64, H = 56;

@@ -57,6 +57,8 @@ def test_golden_features_logits_labels(golden, prec, seed):
     assert np.array_equal(lab.cpu().numpy()[decided], golden[f"s{seed}_labels"][decided])
     assert torch.equal(lab, l.argmax(1))  # in-kernel argmax == torch.argmax of our own logits
     for i, name in enumerate(TAPS):
+        if i == 0:
+            continue  # the stem map is not materialised (fused with the max-pool); see test_unfused_stem_path
         t = net.tap(u8.shape[0], i)[0, :4, :2]
         ref = torch.from_numpy(golden[f"s{seed}_tap_{name}"])
         scale = float(golden[f"s{seed}_tap_absmax"][i])
@@ -74,7 +76,31 @@ def test_full_taps_against_oracle_random_patches(prec):
     f, l, _ = net.forward(x.cuda(), want_feats=True, want_logits=True)
     assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
     for i, name in enumerate(TAPS):
+        if i == 0:
+            with pytest.raises(capi.HipacError):
+                net.tap(5, 0)
+            continue
         assert rel(net.tap(5, i), taps[name]) <= TOL[prec]["tap"], name
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_unfused_stem_path(monkeypatch, prec):
+    """HIPAC_FUSE_STEM=0 runs the separate stem-conv and max-pool kernels: the stem tap
+    exists there, and the fused kernel must reproduce its results bit for bit."""
+    sd = synth.seeded_resnet18_state_dict(2, num_classes=2)
+    u8 = synth.synth_patches_u8(5, seed=11)
+    x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+    taps = {}
+    R.resnet18_forward(x, sd, taps)
+    net = capi.PackedResNet18(sd, precision=prec)
+    f_fused, l_fused, _ = net.forward(x.cuda(), want_logits=True)
+    pool_fused = net.tap(5, 1).clone()
+    monkeypatch.setenv("HIPAC_FUSE_STEM", "0")
+    net2 = capi.PackedResNet18(sd, precision=prec)
+    f_sep, l_sep, _ = net2.forward(x.cuda(), want_logits=True)
+    assert rel(net2.tap(5, 0), taps["stem"]) <= TOL[prec]["tap"]
+    assert torch.equal(net2.tap(5, 1), pool_fused)
+    assert torch.equal(f_sep, f_fused) and torch.equal(l_sep, l_fused)
 
 
 def test_native_layout_equals_nchw_path_bitwise():
