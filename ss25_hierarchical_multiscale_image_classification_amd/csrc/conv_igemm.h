@@ -861,6 +861,167 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// layer1 kernel: 3x3 / stride 1 / 64 -> 64 channels on the 56x56 map (4 of the 20 convs,
+// 25 % of the FLOPs, and the largest activations after the stem).
+//   * persistent workgroups (grid-stride over work units), 4 waves
+//   * a unit = two 8x8 output tiles; each tile's 10x10 input halo (64 ch = 128 B per pixel)
+//     is brought into LDS by LDS-DMA: 200 pixels per 128 outputs = 1.56x re-read
+//   * K = 576 is short enough for every lane to keep ITS weight fragments for all 9 taps in
+//     registers (36 fragments = 144 VGPRs; wave = one tile x 32 channels), so weights are
+//     fetched once per workgroup and LDS serves only activation fragments, with NO barrier
+//     inside a unit's 72-MFMA loop
+//   * LDS placement of halo pixel (hy,hx): slot hy*10+hx, 16-byte chunk c stored at
+//     c ^ (((hx>>1)&1) | ((hy&3)<<1)).  For every tap, a ds_read_b128 lane group (4 runs of 4
+//     consecutive x on 4 consecutive rows) then hits 16 distinct 16-byte slots: conflict-free
+//   * epilogue staged through LDS as fp32 [pixel][64] so global traffic is whole 128-byte
+//     pixel rows: 16-byte coalesced residual loads and stores; the DMA of the NEXT unit's
+//     halos is issued before the epilogue and overlaps it
+// ---------------------------------------------------------------------------------------
+template <typename T, bool RESID>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                             const float* __restrict__ bias,
+                                                             const T* __restrict__ resid, T* __restrict__ out,
+                                                             int n_tiles, const char* __restrict__ zero_page) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int H = 56, W = 56, C = 64, TPI = 49;  // 7 x 7 tiles of 8 x 8 per image
+  constexpr int HALO = 10, HPIECES = 13;           // 100 halo pixels -> 13 pieces of 8
+  constexpr int H_BYTES = HPIECES * 1024;
+  constexpr int SROW = 272;                        // staging row: 64 fp32 + 16 B pad
+  constexpr int S_BYTES = 128 * SROW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * H_BYTES + S_BYTES];
+  unsigned char* const Sl = smem + 2 * H_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave & 1, wn = wave >> 1;  // tile of the pair, channel half
+  const int r = lane & 31, h = lane >> 5;
+
+  // weights of channels wn*32 + r, all 9 taps x 64 input channels, in registers
+  frag wreg[9][4];
+  {
+    const char* wb = reinterpret_cast<const char*>(wgt) + (size_t)(wn * 32 + r) * (9 * C * 2) + 16 * h;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wreg[tap][kk] = *reinterpret_cast<const frag*>(wb + tap * 128 + kk * 32);
+  }
+  // bias of the 8 channels this thread finalises in the epilogue (item -> c8 = tid & 7 in every pass)
+  const float4 b_lo = *reinterpret_cast<const float4*>(bias + (tid & 7) * 8);
+  const float4 b_hi = *reinterpret_cast<const float4*>(bias + (tid & 7) * 8 + 4);
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const int prow = lane >> 3, dchunk = lane & 7;
+  const char* in_b = reinterpret_cast<const char*>(in);
+
+  // LDS-DMA of the two halos of unit u (tiles 2u, 2u+1); 26 pieces over 4 waves
+  auto issue_unit = [&](int u) {
+    for (int p = wave; p < 2 * HPIECES; p += 4) {
+      const int tsel = p >= HPIECES ? 1 : 0;
+      const int pp = p - tsel * HPIECES;
+      const int tile = 2 * u + tsel;
+      const int q = pp * 8 + prow;             // halo pixel slot 0..103 (>= 100: unused)
+      const int hy = q / HALO, hx = q - hy * HALO;
+      const int b = tile / TPI, t = tile - b * TPI;
+      const int ty = t / 7, tx = t - ty * 7;
+      const int y = ty * 8 + hy - 1, x = tx * 8 + hx - 1;
+      const bool ok = tile < n_tiles && q < HALO * HALO && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
+      const char* src = ok ? in_b + ((((size_t)b * H + y) * W + x) * C + (dchunk ^ sw) * 8) * 2
+                           : zero_page + dchunk * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + tsel * H_BYTES + pp * 1024), 16, 0, 0);
+    }
+  };
+
+  // this lane's two output pixels inside its tile: sub-tile i = rows 4i..4i+3; (ly,lx) = (4i + r/8, r%8)
+  int lx = r & 7, ly0 = r >> 3;
+  const unsigned char* const Hl = smem + wt * H_BYTES;
+
+  const int n_units = (n_tiles + 1) >> 1;
+  int u = blockIdx.x;
+  if (u < n_units) issue_unit(u);
+  for (; u < n_units; u += gridDim.x) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // both halos landed (and the previous unit's epilogue is finished)
+
+    // keep the 18 tap address bases from being hoisted out of the unit loop (they would
+    // cost 18 VGPRs next to 144 of weights): make their inputs opaque per iteration
+    asm volatile("" : "+v"(lx), "+v"(ly0));
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      int abase[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hy = 4 * i + ly0 + kh, hx = lx + kw;
+        const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
+        abase[i] = ((hy * HALO + hx) << 7) | ((sw ^ h) << 4);  // chunk (2kk+h) ^ sw = (2kk) ^ (h ^ sw)
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const frag af = *reinterpret_cast<const frag*>(Hl + (abase[i] ^ (kk << 5)));
+          acc[i] = E::mfma(wreg[tap][kk], af, acc[i]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the halos: start the next unit's DMA
+    if (u + (int)gridDim.x < n_units) issue_unit(u + gridDim.x);
+
+    // phase 1: accumulators -> fp32 staging tile [pixel = wt*64 + 32i + r][channel]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = acc[i][4 * q + 0];
+        v[1] = acc[i][4 * q + 1];
+        v[2] = acc[i][4 * q + 2];
+        v[3] = acc[i][4 * q + 3];
+        *reinterpret_cast<f32x4*>(Sl + (wt * 64 + 32 * i + r) * SROW + (wn * 32 + 8 * q + 4 * h) * 4) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // raw barrier: a __syncthreads() here would drain the DMA in flight
+    // phase 2: + bias (+ residual) ReLU -> T, whole pixel rows: 8 lanes x 16 B per pixel
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int item = tid + 256 * pass;
+      const int px = item >> 3, c8 = item & 7;     // px 0..127: tile px>>6, pixel px&63
+      const int tile = 2 * u + (px >> 6);
+      if (tile < n_tiles) {
+        const int b = tile / TPI, t = tile - b * TPI;
+        const int ty = t / 7, tx = t - ty * 7;
+        const int y = ty * 8 + ((px & 63) >> 3), x = tx * 8 + (px & 7);
+        const size_t o = ((((size_t)b * H + y) * W + x) * C + c8 * 8);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32 + 16);
+        float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
+                      hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
+        if constexpr (RESID) {
+          const frag rv = *reinterpret_cast<const frag*>(resid + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        frag ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (T)fmaxf(v[e], 0.f);
+        *reinterpret_cast<frag*>(out + o) = ov;
+      }
+    }
+  }
+}
+
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
 // post-ReLU (>= 0) so the implicit -inf padding never wins; out-of-range taps
 // are simply skipped.
@@ -900,6 +1061,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
   *reinterpret_cast<frag*>(out + (((size_t)b * HO + oh) * WO + ow) * C + c8 * 8) = o;
 }
 
+#ifndef HIPAC_USE_C64
+#define HIPAC_USE_C64 1
+#endif
 #ifndef HIPAC_USE_HALO
 #define HIPAC_USE_HALO 1
 #endif
@@ -933,6 +1097,12 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     dim3 grid((M + 127) / 128, COUT / BN);
     hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
                        grid, dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M);
+  } else if constexpr (HIPAC_USE_C64 && KS == 3 && STRIDE == 1 && CIN == 64 && COUT == 64 && HI == 56 && RELU && !OUTF32) {
+    const int n_tiles = n * 49;
+    const int n_units = (n_tiles + 1) / 2;
+    const int grid = n_units < 512 ? n_units : 512;  // persistent, 2 workgroups per CU
+    hipLaunchKernelGGL((conv3x3_c64_kernel<T, RESID>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w,
+                       w.bias, (const T*)resid, (T*)out, n_tiles, zero_page);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
     constexpr int BM = 128, BN = COUT >= 128 ? 128 : 64;
     constexpr int A_BYTES = ((halo_rows_max<HI, WI, BM>() * (WI + 2) + 7) / 8) * 1024;
