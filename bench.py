@@ -55,10 +55,10 @@ assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 def per_op_times(net: capi.PackedResNet18, dev, reps: int = 20):
     """Average launch duration (ms) of every trunk kernel, HIP events on torch's current
     stream == the stream the library launches on.  Early ops (stem..layer2) run on one
-    sub-batch (512 images), late ops (layer3, layer4) on one group (2048 images), exactly
+    sub-batch (512 images), late ops (layer3, layer4) on one group (4096 images), exactly
     as inside hipac_resnet18_forward."""
     bc = int(os.environ.get("HIPAC_SUBBATCH", "512"))
-    gc = max(int(os.environ.get("HIPAC_GROUP", "2048")), bc)
+    gc = max(int(os.environ.get("HIPAC_GROUP", "4096")), bc)
     x = torch.randn(gc, 3, 224, 224, device=dev)
     net.forward(x, want_feats=True)  # fills the workspace with real activations
     del x

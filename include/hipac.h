@@ -126,7 +126,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
  * activations a previous hipac_resnet18_forward(in_layout = NCHW) left in `workspace`.
  * Ops 0..10 (stem, pool, layer1, layer2) act on the first internal sub-batch
  * (min(batch, 512) images), ops 11..20 (layer3, layer4) on all `batch` images, which
- * must fit one internal group (2048).  Used by bench.py to time single kernels with
+ * must fit one internal group (4096).  Used by bench.py to time single kernels with
  * events on the caller's stream; not part of the reference's surface. */
 int hipac_resnet18_run_ops(const hipac_weights_t* w, void* workspace, size_t workspace_bytes, int batch,
                            int first_op, int last_op, void* stream);

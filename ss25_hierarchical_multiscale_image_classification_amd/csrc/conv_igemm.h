@@ -481,28 +481,40 @@ constexpr int halo_rows_max() {
   return best;
 }
 
-template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, bool RELU, bool RESID, bool OUTF32>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
-                                                           const float* __restrict__ bias,
-                                                           const T* __restrict__ resid, void* __restrict__ outp,
-                                                           int M, int n_img, int n_mtiles,
-                                                           const char* __restrict__ zero_page) {
+// Band layout (v3b): the band is stored WITHOUT halo columns: slot 1 + row*W + x (slot 0 is
+// a pixel of zeros).  Consecutive output pixels then sit in consecutive slots even across
+// row wraps, so the swizzle stays conflict-free for every tap; a tap that falls left/right
+// of the image row reads slot 0 instead (same address in all such lanes: an LDS broadcast).
+// NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
+// Epilogue: the 128 x BN fp32 tile goes through LDS in two halves of 64 pixels so that
+// global traffic is 16-byte pieces of whole pixel rows (residual loads and stores).
+template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                              const float* __restrict__ bias,
+                                                              const T* __restrict__ resid, void* __restrict__ outp,
+                                                              int M, int n_img, int n_mtiles,
+                                                              const char* __restrict__ zero_page) {
   using E = Elem<T>;
   using frag = typename E::frag;
   constexpr int CC = CIN / 64;
   constexpr int KTOT = 9 * CIN;
-  constexpr int WP = W + 2, HPAD = H + 2;
-  constexpr int WM = BM / 64, WN = 4 / WM;          // 4 waves: WM x WN
+  constexpr int HPAD = H + 2;
+  constexpr int WM = 2, WN = 2;                     // 4 waves: 2 pixel halves x 2 channel halves
+  constexpr int MTW = BM / (WM * 32);               // 32-pixel sub-tiles per wave (2 or 4)
   constexpr int WTN = BN / WN, NT = WTN / 32;       // channels per wave, 32-wide tiles per wave
   constexpr int ROWS_MAX = halo_rows_max<H, W, BM>();
-  constexpr int A_PIECES = (ROWS_MAX * WP + 7) / 8;
+  constexpr int A_PIECES = (ROWS_MAX * W + 2 + 7) / 8;
   constexpr int A_BYTES = A_PIECES * 1024;
   constexpr int W_BYTES = BN * 128;
   constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
   constexpr int NTILES_N = COUT / BN;
-  static_assert(BM % 64 == 0 && WM * WN == 4 && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
+  constexpr int NSTEP = 9 * CC;
+  constexpr int SROW = BN * 4 + 16;                  // epilogue staging row (fp32 + pad), bytes
+  static_assert((BM == 128 || BM == 256) && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
   static_assert((BN / 8) % 4 == 0, "W piece split");
-  static_assert(A_BYTES + 2 * W_BYTES <= 160 * 1024, "LDS");
+  static_assert(NSW == 2 || NSW == 3, "weight ring depth");
+  static_assert(A_BYTES + NSW * W_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
+  static_assert(64 * SROW <= A_BYTES + NSW * W_BYTES, "epilogue staging aliases the band + ring");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   unsigned char* const Abuf = ring;
@@ -526,8 +538,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
   const int b_first = m0 / (H * W), b_last = mlast / (H * W);
   const int rp_lo = b_first * HPAD + (m0 - b_first * (H * W)) / W;
   const int rp_hi = b_last * HPAD + (mlast - b_last * (H * W)) / W + 2;
-  const int npx = (rp_hi - rp_lo + 1) * WP;      // <= ROWS_MAX * WP by construction
-  const int npieces = (npx + 7) >> 3;
+  const int npx = (rp_hi - rp_lo + 1) * W;       // real band pixels; slots 1..npx
+  const int npieces = (npx + 2 + 7) >> 3;
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -535,15 +547,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
   const char* w_b = reinterpret_cast<const char*>(wgt);
   const int prow = lane >> 3, dchunk = lane & 7;
 
-  // DMA of the band for channel chunk cc (all 4 waves, piece p -> wave p % 4)
   auto issue_band = [&](int cc) {
     for (int p = wave; p < npieces; p += 4) {
-      const int q = p * 8 + prow;
-      const int rr = q / WP, cx = q - rr * WP;
+      const int q = p * 8 + prow;                // slot
+      const int idx = q - 1;
+      const int rr = idx / W, x = idx - rr * W;
       const int rp = rp_lo + rr;
-      const int b = rp / HPAD, py = rp - b * HPAD;
-      const int y = py - 1, x = cx - 1;
-      const bool ok = q < npx && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && b < n_img;
+      const int b = rp / HPAD, y = rp - b * HPAD - 1;
+      const bool ok = q >= 1 && idx < npx && (unsigned)y < (unsigned)H && b < n_img;
       const int schunk = dchunk ^ ((q >> 1) & 7);
       const char* src = ok ? in_b + ((((size_t)b * H + y) * W + x) * CIN + cc * 64 + schunk * 8) * 2
                            : zero_page + dchunk * 16;
@@ -556,7 +567,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     const int row = (wave + 4 * i) * 8 + prow;
     w_off[i] = ((n0 + row) * KTOT + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
   }
-  auto issue_w = [&](int kofs_bytes, int slot_) {
+  auto issue_w = [&](int step, int slot_) {  // weights of step = cc*9 + tap: K offset (tap*CIN + cc*64)
+    const int cc = step / 9, tap = step - cc * 9;
+    const int kofs_bytes = (tap * CIN + cc * 64) * 2;
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       __builtin_amdgcn_global_load_lds((gptr_t)(w_b + (w_off[i] + kofs_bytes)),
@@ -564,16 +577,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     });
   };
 
-  // ---- consumer side: band pixel of this lane's two output pixels (tap 0,0) -------------
-  int q0[2];
+  // ---- consumer side: slot of this lane's two output pixels for tap (0, centre column) ----
+  int q0[MTW];
+  bool edgeL[MTW], edgeR[MTW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + wm * 64 + i * 32 + r;
+  for (int i = 0; i < MTW; ++i) {
+    int m = m0 + wm * (MTW * 32) + i * 32 + r;
     m = m <= mlast ? m : mlast;  // tail lanes read a valid pixel; their results are not stored
     const int b = m / (H * W);
     const int rem = m - b * (H * W);
     const int y = rem / W, x = rem - y * W;
-    q0[i] = (b * HPAD + y - rp_lo) * WP + x;
+    q0[i] = 1 + (b * HPAD + y - rp_lo) * W + x;   // tap (kh,kw) -> q0 + kh*W + kw - 1
+    edgeL[i] = x == 0;
+    edgeR[i] = x == W - 1;
   }
   const int sw_w = (r >> 1) & 7;
   int rdw[4], ck[4];
@@ -583,48 +599,68 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     rdw[kk] = (wn * WTN + r) * 128 + (((2 * kk + h) ^ sw_w) << 4);
   }
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MTW][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // step s = cc*9 + tap; the weights' K offset of step s is ((tap)*CIN + cc*64) elements
-  auto kofs = [&](int cc, int tap) { return (tap * CIN + cc * 64) * 2; };
-
   issue_band(0);
-  issue_w(kofs(0, 0), 0);
+#pragma unroll
+  for (int pstep = 0; pstep < NSW - 1; ++pstep)
+    if (pstep < NSTEP) issue_w(pstep, pstep);
   int s = 0;
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0) {
-      // every wave has finished reading the previous chunk's band (lgkmcnt(0) below + this barrier)
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
       issue_band(cc);
     }
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++s) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();  // band (tap 0) and W(s) landed for every wave; W slot (s+1)&1 is free
-      {
-        const int ntap = tap + 1 == 9 ? 0 : tap + 1;
-        const int ncc = tap + 1 == 9 ? cc + 1 : cc;
-        if (ncc < CC) issue_w(kofs(ncc, ntap), (s + 1) & 1);
-      }
+      // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
+      if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
+      else wait_vmcnt<0>();
+#ifndef HIPAC_ABL_NO_BARRIER
+      __builtin_amdgcn_s_barrier();
+#endif
+#ifndef HIPAC_ABL_NO_W_DMA
+      if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+#endif
       const int kh = tap / 3, kw = tap - kh * 3;
-      const int toff = kh * WP + kw;
-      const unsigned char* wst = Wbuf + (s & 1) * W_BYTES;
-      int abase[2], asw[2];
+      const int toff = kh * W + kw - 1;
+      const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+      int abase[MTW], asw[MTW];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int q = q0[i] + toff;
+      for (int i = 0; i < MTW; ++i) {
+        const bool off_row = (kw == 0 && edgeL[i]) || (kw == 2 && edgeR[i]);
+        const int q = off_row ? 0 : q0[i] + toff;   // slot 0 = zeros
         abase[i] = q << 7;
         asw[i] = ((q >> 1) & 7) << 4;
       }
-      frag af[2][2], wf[2][NT];
+      frag af[2][MTW], wf[2][NT];
+#ifdef HIPAC_ABL_NO_LDSREAD
+      {
+        const frag c0 = __builtin_bit_cast(frag, u32x4{(unsigned)abase[0], (unsigned)asw[0], (unsigned)toff, 1u});
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[0] ^ asw[i]));
+        for (int i = 0; i < MTW; ++i) af[0][i] = af[1][i] = c0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[0][j] = wf[1][j] = c0;
+        (void)wst;
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      continue;
+#endif
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) af[0][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[0] ^ asw[i]));
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[0][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[0]);
       __builtin_amdgcn_s_setprio(1);
@@ -632,14 +668,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
       for (int kk = 0; kk < 4; ++kk) {
         if (kk + 1 < 4) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MTW; ++i)
             af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[kk + 1] ^ asw[i]));
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[kk + 1]);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
       }
@@ -648,44 +684,63 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     }
   }
 
-  // ---- epilogue: +bias (+residual) (ReLU) -> NHWC store ---------------------------------
+  // ---- epilogue through LDS: BM/64 parts of 64 pixels ------------------------------------
+  // phase 1 (the two waves owning the half): accumulators -> fp32 [64 px][BN] rows of SROW B
+  // phase 2 (all threads): + bias (+ residual) (ReLU) -> 16 B of T (32 B of fp32) per item
+  constexpr int CPR = BN / 8;                       // 8-channel items per pixel row
+  constexpr int ITEMS = 64 * CPR;
+  unsigned char* const Sl = ring;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + r;
-    if (m >= M) continue;
+  for (int part = 0; part < BM / 64; ++part) {
+    __builtin_amdgcn_s_barrier();  // K loop reads (part 0) / the previous part's phase 2 are done
+    if (wm == part / (MTW / 2)) {  // the two waves (wn = 0,1) that own these 64 pixels
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = n0 + wn * WTN + j * 32 + 8 * q + 4 * h;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-        float v0 = acc[i][j][4 * q + 0] + bv.x;
-        float v1 = acc[i][j][4 * q + 1] + bv.y;
-        float v2 = acc[i][j][4 * q + 2] + bv.z;
-        float v3 = acc[i][j][4 * q + 3] + bv.w;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = (part % (MTW / 2)) * 2 + ii;  // compile-time after unrolling
+            f32x4 v;
+            v[0] = acc[i][j][4 * q + 0];
+            v[1] = acc[i][j][4 * q + 1];
+            v[2] = acc[i][j][4 * q + 2];
+            v[3] = acc[i][j][4 * q + 3];
+            *reinterpret_cast<f32x4*>(Sl + (32 * ii + r) * SROW + (wn * WTN + j * 32 + 8 * q + 4 * h) * 4) = v;
+          }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int item = tid; item < ITEMS; item += 256) {
+      const int px = item / CPR, c8 = item - px * CPR;
+      const int m = m0 + part * 64 + px;
+      if (m < M) {
+        const int c0 = n0 + c8 * 8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32 + 16);
+        const float4 b_lo = *reinterpret_cast<const float4*>(bias + c0);
+        const float4 b_hi = *reinterpret_cast<const float4*>(bias + c0 + 4);
+        float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
+                      hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
         const size_t o = (size_t)m * COUT + c0;
         if constexpr (RESID) {
-          const typename E::vec4 rv = *reinterpret_cast<const typename E::vec4*>(resid + o);
-          v0 += (float)rv[0];
-          v1 += (float)rv[1];
-          v2 += (float)rv[2];
-          v3 += (float)rv[3];
+          const frag rv = *reinterpret_cast<const frag*>(resid + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
         }
         if constexpr (RELU) {
-          v0 = fmaxf(v0, 0.f);
-          v1 = fmaxf(v1, 0.f);
-          v2 = fmaxf(v2, 0.f);
-          v3 = fmaxf(v3, 0.f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if constexpr (OUTF32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + o) = make_float4(v0, v1, v2, v3);
+          float* op = reinterpret_cast<float*>(outp) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-          typename E::vec4 ov;
-          ov[0] = (T)v0;
-          ov[1] = (T)v1;
-          ov[2] = (T)v2;
-          ov[3] = (T)v3;
-          *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp) + o) = ov;
+          frag ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (T)v[e];
+          *reinterpret_cast<frag*>(reinterpret_cast<T*>(outp) + o) = ov;
         }
       }
     }
@@ -1061,6 +1116,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
   *reinterpret_cast<frag*>(out + (((size_t)b * HO + oh) * WO + ow) * C + c8 * 8) = o;
 }
 
+#ifndef HIPAC_HALO_BM256
+#define HIPAC_HALO_BM256 1
+#endif
 #ifndef HIPAC_USE_C64
 #define HIPAC_USE_C64 1
 #endif
@@ -1104,10 +1162,15 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     hipLaunchKernelGGL((conv3x3_c64_kernel<T, RESID>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w,
                        w.bias, (const T*)resid, (T*)out, n_tiles, zero_page);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
-    constexpr int BM = 128, BN = COUT >= 128 ? 128 : 64;
-    constexpr int A_BYTES = ((halo_rows_max<HI, WI, BM>() * (WI + 2) + 7) / 8) * 1024;
-    constexpr int LDS = A_BYTES + 2 * BN * 128;
-    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, RELU, RESID, OUTF32>;
+    constexpr int BN = COUT >= 128 ? 128 : 64;
+    // 256-pixel tiles (each wave 128 px x 64 ch: 0.75 LDS reads per MFMA, half the weight DMA per
+    // FLOP) wherever the band still leaves room for two workgroups per CU; else 128
+    constexpr int A256 = ((halo_rows_max<HI, WI, 256>() * WI + 2 + 7) / 8) * 1024;
+    constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
+    constexpr int A_BYTES = ((halo_rows_max<HI, WI, BM>() * WI + 2 + 7) / 8) * 1024;
+    constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;  // deepest ring that keeps 2 workgroups/CU
+    constexpr int LDS = A_BYTES + NSW * BN * 128;
+    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32>;
     static bool attr_done = false;
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

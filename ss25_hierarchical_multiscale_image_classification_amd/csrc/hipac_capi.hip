@@ -51,10 +51,10 @@ Plan make_plan(int batch) {
   Plan p;
   // bc: early sub-batch -- 512 images give layer1/2 thousands of tiles (block-round
   // quantisation < 10 %).  gc: late group -- layer4 has only 49 pixels per image, so it
-  // needs ~2048 images to fill 256 CUs x 2 workgroups for several rounds.
+  // needs thousands of images (default group 4096) to fill 256 CUs x 2 workgroups for several rounds.
   // (tuning knobs; a whole run must use one setting)
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
-  const int gc_cap = env_int("HIPAC_GROUP", 2048, 1, 4096);
+  const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
   p.fuse_stem = env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
