@@ -50,6 +50,10 @@ extern "C" {
                                  224x224 image at rows 3..226, cols 3..226, channel 3 and the
                                  border all zero.  Written directly by hipac_tile_preprocess. */
 
+#define HIPAC_IN_U8_HWC 2     /* uint8[B,224,224,3] raw RGB patches (e.g. hipac_tile_preprocess's
+                                 HIPAC_OUT_U8_HWC): ToTensor + Normalize (src/main.py:815-816) are
+                                 applied inside the stem kernel, bit-identical to the other paths */
+
 /* output formats of hipac_tile_preprocess */
 #define HIPAC_OUT_NCHW_F32 0     /* float32[n,3,224,224] == Resize->ToTensor->Normalize */
 #define HIPAC_OUT_NHWC4_PAD_BF16 1

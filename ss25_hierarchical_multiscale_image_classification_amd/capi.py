@@ -20,7 +20,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")  # override: A/B builds of the same ABI
 
 PREC_BF16, PREC_FP16 = 0, 1
-IN_NCHW_F32, IN_NHWC4_PAD = 0, 1
+IN_NCHW_F32, IN_NHWC4_PAD, IN_U8_HWC = 0, 1, 2
 OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
 PATCH, PAD_H, PAD_W = 224, 230, 232
 
@@ -251,10 +251,16 @@ class PackedResNet18:
         want_labels: bool = False,
         native_layout: bool = False,
     ):
-        """x: float32[B,3,224,224] on cuda, or (native_layout) T[B,230,232,4].
+        """x: float32[B,3,224,224] on cuda, or (native_layout) T[B,230,232,4], or raw
+        uint8[B,224,224,3] patches (ToTensor/Normalize fused into the stem kernel).
         Returns (feats|None, logits|None, labels|None), all on x's device."""
         _require_gpu(x)
-        if native_layout:
+        layout = IN_NHWC4_PAD if native_layout else IN_NCHW_F32
+        if x.dtype == torch.uint8:
+            if tuple(x.shape[1:]) != (PATCH, PATCH, 3):
+                raise HipacError(f"uint8 input must be [B,224,224,3], got {tuple(x.shape)}")
+            layout = IN_U8_HWC
+        elif native_layout:
             if tuple(x.shape[1:]) != (PAD_H, PAD_W, 4) or x.dtype != TORCH_DTYPE[PRECISIONS[self.precision]]:
                 raise HipacError(f"native input must be {self.precision}[B,{PAD_H},{PAD_W},4], got {x.dtype}{tuple(x.shape)}")
         else:
@@ -272,7 +278,7 @@ class PackedResNet18:
         ws = self.workspace(B, dev)
         with torch.cuda.device(dev):
             rc = self._lib.hipac_resnet18_forward(
-                self.handle, x.data_ptr(), B, IN_NHWC4_PAD if native_layout else IN_NCHW_F32,
+                self.handle, x.data_ptr(), B, layout,
                 _ptr(feats), _ptr(logits), _ptr(labels), ws.data_ptr(), ws.numel(), _stream())
         _check(rc, "hipac_resnet18_forward")
         return feats, logits, labels

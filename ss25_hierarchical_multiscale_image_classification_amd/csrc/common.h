@@ -74,6 +74,7 @@ struct Net {
   float* fc_w;  // device float[num_classes][512]
   float* fc_b;
   char* zero_page;  // device, 256 zero bytes: DMA source for out-of-image conv taps
+  unsigned short* lut_t;  // device, T[3][256]: (v/255 - mean)/std in fp32, rounded to T (uint8 input path)
 };
 
 // Workspace plan.  The trunk runs in two phases so every launch fills the chip:
@@ -82,6 +83,7 @@ struct Net {
 // Offsets are bytes into the caller's workspace; T = 2-byte element.
 struct Plan {
   int bc, gc;
+  int u8_input;   // 1: the stem reads raw uint8 HWC patches (normalise fused); needs fuse_stem
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]

@@ -762,10 +762,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 // Stem pixels outside the image (row/col -1) are stored as 0: inputs are post-ReLU (>= 0),
 // so they can never win the max.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__ xin, const T* __restrict__ wgt,
+// U8IN: the input is the raw uint8 HWC patch batch [n,224,224,3]; ToTensor/Normalize is
+// applied while the patch is staged (a 3 x 256 table of T values in LDS == the fp32 LUT
+// rounded to T, i.e. exactly what hipac_patches_normalize would have written), so the padded
+// NHWC4 tensor (427 KB per patch written and read back) never exists.
+template <typename T, bool U8IN>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin_, const T* __restrict__ wgt,
                                                         const float* __restrict__ bias, T* __restrict__ out,
-                                                        int n_tiles) {
+                                                        int n_tiles, const unsigned short* __restrict__ lut_t,
+                                                        long long in_bytes) {
+  const T* xin = reinterpret_cast<const T*>(xin_);
   using E = Elem<T>;
   using frag = typename E::frag;
   constexpr int PTH = 8, PTW = 7;                                       // pooled tile
@@ -777,12 +783,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__
   constexpr int TILES_X = 56 / PTW, TILES_Y = 56 / PTH, TPI = TILES_X * TILES_Y;  // 8 x 7 = 56 per image
   constexpr int SPX = 144;  // stem-tile pixel stride in LDS: 128 B of channels + 16 B pad (bank spread)
   constexpr int P_BYTES = PROWS * PCOLS * 8, S_BYTES = 256 * SPX;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + S_BYTES];
+  constexpr int RAWROW = 112, RAWDW = RAWROW / 4;                       // raw uint8 window per patch row
+  constexpr int RAW_BYTES = U8IN ? PROWS * RAWROW + 3 * 256 * 2 : 0;    // + the T-typed normalise table
+  constexpr int NRAW = PROWS * RAWDW, PFR = (NRAW + 255) / 256;          // 1092 dwords, 5 per thread
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + S_BYTES + RAW_BYTES];
   unsigned char* const Sl = smem + 2 * P_BYTES;
+  unsigned char* const Rl = smem + 2 * P_BYTES + S_BYTES;
+  unsigned short* const Ll = reinterpret_cast<unsigned short*>(Rl + PROWS * RAWROW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  if constexpr (U8IN) {
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) Ll[i] = lut_t[i];
+  }
   // this lane's rows of the weight matrix, all of K, in registers for the kernel's lifetime
   frag wreg[2][7][2];
   {
@@ -819,34 +833,89 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__
     py0 = ty * PTH;
     px0 = (t - ty * TILES_X) * PTW;
   };
-  u32x4 pre[PF];
+  u32x4 pre[U8IN ? 1 : PF];
+  unsigned praw[U8IN ? PFR : 1];
   auto fetch = [&](int tile) {  // global -> registers: the input patch of `tile`
     int b, py0, px0;
     tile_origin(tile, b, py0, px0);
     const int R0 = 2 * (2 * py0 - 1), C0 = 2 * (2 * px0 - 1);
-    const char* img = reinterpret_cast<const char*>(xin) + (size_t)b * kPadH * kPadW * 8;
-    static_for<PF>([&](auto I) {
-      constexpr int k = decltype(I)::value;
-      const int i = tid + 256 * k;
-      const int row = i / PPR, cp = i - row * PPR;
-      const int R = R0 + row, C = C0 + 2 * cp;
-      const bool ok = i < NPIECE && R >= 0 && C >= 0;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(img + (ok ? ((size_t)R * kPadW + C) * 8 : 0));
-      pre[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
-    });
+    if constexpr (U8IN) {
+      // raw bytes of image rows R0-3 .. , columns C0-3 .. C0+32, as aligned dwords
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(xin_);
+      static_for<PFR>([&](auto I) {
+        constexpr int k = decltype(I)::value;
+        const int i = tid + 256 * k;
+        const int row = i / RAWDW, j = i - row * RAWDW;
+        const int y = R0 + row - 3;
+        const long long off0 = (((long long)b * kPatch + y) * kPatch + (C0 - 3)) * 3;
+        const long long off = off0 - (off0 & 3) + 4 * j;
+        const bool ok = i < NRAW && (unsigned)y < (unsigned)kPatch && off >= 0 && off + 4 <= in_bytes;
+        const unsigned v = *reinterpret_cast<const unsigned*>(src + (ok ? off : 0));
+        praw[k] = ok ? v : 0u;
+      });
+    } else {
+      const char* img = reinterpret_cast<const char*>(xin) + (size_t)b * kPadH * kPadW * 8;
+      static_for<PF>([&](auto I) {
+        constexpr int k = decltype(I)::value;
+        const int i = tid + 256 * k;
+        const int row = i / PPR, cp = i - row * PPR;
+        const int R = R0 + row, C = C0 + 2 * cp;
+        const bool ok = i < NPIECE && R >= 0 && C >= 0;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(img + (ok ? ((size_t)R * kPadW + C) * 8 : 0));
+        pre[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      });
+    }
   };
-  auto stash = [&](int buf) {  // registers -> LDS patch buffer
-    static_for<PF>([&](auto I) {
-      constexpr int k = decltype(I)::value;
-      const int i = tid + 256 * k;
-      if (i < NPIECE) *reinterpret_cast<u32x4*>(smem + buf * P_BYTES + i * 16) = pre[k];
-    });
+  auto stash = [&](int buf) {  // registers -> LDS (patch buffer, or the raw window when U8IN)
+    if constexpr (U8IN) {
+      static_for<PFR>([&](auto I) {
+        constexpr int k = decltype(I)::value;
+        const int i = tid + 256 * k;
+        if (i < NRAW) *reinterpret_cast<unsigned*>(Rl + i * 4) = praw[k];
+      });
+    } else {
+      static_for<PF>([&](auto I) {
+        constexpr int k = decltype(I)::value;
+        const int i = tid + 256 * k;
+        if (i < NPIECE) *reinterpret_cast<u32x4*>(smem + buf * P_BYTES + i * 16) = pre[k];
+      });
+    }
+  };
+  // U8IN only: raw window -> normalised T NHWC4 patch (pairs of pixels = 16-byte pieces)
+  auto convert = [&](int tile, int buf) {
+    int b, py0, px0;
+    tile_origin(tile, b, py0, px0);
+    const int R0 = 2 * (2 * py0 - 1), C0 = 2 * (2 * px0 - 1);
+    for (int i = tid; i < NPIECE; i += 256) {
+      const int row = i / PPR, cp = i - row * PPR;
+      const int y = R0 + row - 3;
+      const long long off0 = (((long long)b * kPatch + y) * kPatch + (C0 - 3)) * 3;
+      const int sh = (int)(off0 & 3);
+      const unsigned char* rr = Rl + row * RAWROW + sh + 6 * cp;  // byte of channel 0 of the first pixel
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)y < (unsigned)kPatch) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int x = C0 + 2 * cp + px - 3;
+          if ((unsigned)x < (unsigned)kPatch) {
+            const unsigned c0 = Ll[rr[3 * px + 0]], c1 = Ll[256 + rr[3 * px + 1]], c2 = Ll[512 + rr[3 * px + 2]];
+            v[2 * px] = c0 | (c1 << 16);
+            v[2 * px + 1] = c2;
+          }
+        }
+      }
+      *reinterpret_cast<u32x4*>(smem + buf * P_BYTES + i * 16) = v;
+    }
   };
 
   int tile = blockIdx.x;
   if (tile < n_tiles) {
     fetch(tile);
     stash(0);
+    if constexpr (U8IN) {
+      __syncthreads();
+      convert(tile, 0);
+    }
   }
   __syncthreads();
   for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
@@ -894,8 +963,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__
           *reinterpret_cast<typename E::vec4*>(Sl + P[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = ov;
         }
     }
-    __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]... (see below)
-    if (more) stash(buf ^ 1);  // patch[buf^1] was last read by the MFMAs of the previous iteration
+    __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]
+    if (more) stash(buf ^ 1);  // patch[buf^1] (raw window) was last read in the previous iteration
     // 3x3/2 max-pool of the tile: pooled pixel x 8 channels per thread item
     for (int item = tid; item < PTH * PTW * 8; item += 256) {
       const int pp = item >> 3, c8 = item & 7;
@@ -912,7 +981,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const T* __restrict__
       const frag o = __builtin_bit_cast(frag, best);
       *reinterpret_cast<frag*>(out + (((size_t)b * 56 + py0 + py) * 56 + px0 + px) * 64 + c8 * 8) = o;
     }
-    __syncthreads();  // pooling reads done (stem tile free) and patch[buf ^ 1] visible
+    __syncthreads();  // pooling reads done (stem tile free) and patch[buf ^ 1] / raw window visible
+    if constexpr (U8IN) {
+      if (more) convert(tile + gridDim.x, buf ^ 1);
+      __syncthreads();
+    }
   }
 }
 
@@ -1257,8 +1330,13 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     if (ops.take()) {
       const int n_tiles = ne * 56;
       const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent: 2 workgroups per CU
-      hipLaunchKernelGGL((stem_pool_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)xin, (const T*)net.stem.w,
-                         net.stem.bias, (T*)(ws + p.pool), n_tiles);
+      if (p.u8_input)
+        hipLaunchKernelGGL((stem_pool_kernel<T, true>), dim3(grid), dim3(256), 0, s, xin, (const T*)net.stem.w,
+                           net.stem.bias, (T*)(ws + p.pool), n_tiles, net.lut_t,
+                           (long long)ne * kPatch * kPatch * 3);
+      else
+        hipLaunchKernelGGL((stem_pool_kernel<T, false>), dim3(grid), dim3(256), 0, s, xin, (const T*)net.stem.w,
+                           net.stem.bias, (T*)(ws + p.pool), n_tiles, (const unsigned short*)nullptr, 0LL);
       HIPAC_TRY((int)hipGetLastError());
     }
     (void)ops.take();

@@ -56,6 +56,7 @@ Plan make_plan(int batch) {
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
   const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
   p.fuse_stem = env_int("HIPAC_FUSE_STEM", 1, 0, 1);
+  p.u8_input = 0;
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -270,6 +271,7 @@ void hipac_weights_free(hipac_weights_t* w) {
   if (w->net.fc_w) (void)hipFree(w->net.fc_w);
   if (w->net.fc_b) (void)hipFree(w->net.fc_b);
   if (w->net.zero_page) (void)hipFree(w->net.zero_page);
+  if (w->net.lut_t) (void)hipFree(w->net.lut_t);
   delete w;
 }
 
@@ -300,6 +302,19 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     const char zeros[256] = {0};
     rc = upload(zeros, sizeof(zeros), (void**)&w->net.zero_page);
   }
+  if (!rc) {
+    // ToTensor + Normalize table in fp32 with torchvision's op order (v/255, -mean, /std;
+    // reference src/main.py:815-816), then rounded to the network's storage type
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    std::vector<uint16_t> lut(3 * 256);
+    for (int c = 0; c < 3; ++c)
+      for (int v = 0; v < 256; ++v) {
+        const float t = (float)v / 255.0f;
+        const float d = t - mean[c];
+        lut[c * 256 + v] = to_bits(d / stdv[c], precision);
+      }
+    rc = upload(lut.data(), lut.size() * 2, (void**)&w->net.lut_t);
+  }
   if (!rc && params->num_classes > 0) {
     HIPAC_REQUIRE(params->fc_b != nullptr, HIPAC_EINVAL, "pack: fc_b is null");
     rc = upload(params->fc_w, (size_t)params->num_classes * 512 * 4, (void**)&w->net.fc_w);
@@ -326,15 +341,18 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
                            float* logits, int64_t* labels, void* workspace, size_t workspace_bytes, void* stream) {
   HIPAC_REQUIRE(w && x && workspace, HIPAC_EINVAL, "forward: null argument");
   HIPAC_REQUIRE(batch > 0, HIPAC_EINVAL, "forward: batch %d", batch);
-  HIPAC_REQUIRE(in_layout == HIPAC_IN_NCHW_F32 || in_layout == HIPAC_IN_NHWC4_PAD, HIPAC_EINVAL,
-                "forward: unknown in_layout %d", in_layout);
+  HIPAC_REQUIRE(in_layout == HIPAC_IN_NCHW_F32 || in_layout == HIPAC_IN_NHWC4_PAD || in_layout == HIPAC_IN_U8_HWC,
+                HIPAC_EINVAL, "forward: unknown in_layout %d", in_layout);
   HIPAC_REQUIRE(!(logits || labels) || w->net.num_classes > 0, HIPAC_EINVAL,
                 "forward: logits/labels requested but the weights carry no fc (fc = Identity)");
   HIPAC_REQUIRE(((uintptr_t)workspace & 255) == 0, HIPAC_EINVAL, "forward: workspace must be 256-byte aligned");
   HIPAC_REQUIRE(((uintptr_t)x & 15) == 0, HIPAC_EINVAL, "forward: x must be 16-byte aligned");
-  const Plan p = make_plan(batch);
+  Plan p = make_plan(batch);
   HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
                 workspace_bytes, p.total);
+  HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem, HIPAC_EUNSUPPORTED,
+                "forward: uint8 input needs the fused stem (unset HIPAC_FUSE_STEM=0)");
+  p.u8_input = in_layout == HIPAC_IN_U8_HWC;
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const Net& net = w->net;
@@ -349,6 +367,8 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
         int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
                                       net.precision, s);
         HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
+      } else if (in_layout == HIPAC_IN_U8_HWC) {
+        xin = (const char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3;  // raw patches, normalise fused in the stem
       } else {
         xin = (const char*)x + (size_t)(g0 + b0) * in_img_bytes;  // native layout: stem reads the caller's buffer
       }

@@ -175,7 +175,8 @@ def scan_level(slide: DeviceSlide, level: int, **kw) -> LevelScan:
 
 class WSIPatchStream:
     """Iterable over (x, meta) device batches of KEPT windows for the fused path:
-    x in the network's native layout, meta int32[B,4] = (level, x, y, label)."""
+    x = the resized uint8[B,224,224,3] pixels (the network's stem applies
+    ToTensor/Normalize itself), meta int32[B,4] = (level, x, y, label)."""
 
     def __init__(self, slide: DeviceSlide, levels: Sequence[int] = (0, 1, 2, 3), batch_windows: int = 512,
                  precision: str = "bf16", stride: Optional[int] = None):
@@ -184,7 +185,7 @@ class WSIPatchStream:
 
     def __iter__(self):
         for level in self.levels:
-            for part in iter_level(self.slide, level, out_format=self.precision, batch_windows=self.batch_windows,
+            for part in iter_level(self.slide, level, out_format="u8", batch_windows=self.batch_windows,
                                    stride=self.stride):
                 idx = torch.nonzero(part["keep"], as_tuple=False).flatten()
                 xy = part["xy"].index_select(0, idx)
@@ -204,7 +205,7 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     for x, meta in WSIPatchStream(slide, levels, batch_windows, net.precision, stride):
         if x.shape[0] == 0:
             continue
-        f, l, p = net.forward(x, want_feats=True, want_logits=has_fc, want_labels=has_fc, native_layout=True)
+        f, l, p = net.forward(x, want_feats=True, want_logits=has_fc, want_labels=has_fc)
         feats.append(f)
         metas.append(meta)
         if has_fc:

@@ -40,8 +40,7 @@ def extract_features_from_pngs(patch_dir: str, net: capi.PackedResNet18, batch_s
     feats, labels, paths = [], [], []
     for imgs, lbls, pths in loader:
         # group by patch size: one preprocess launch per size present in the batch
-        out = torch.empty((len(imgs), capi.PAD_H, capi.PAD_W, 4),
-                          dtype=capi.TORCH_DTYPE[capi.PRECISIONS[net.precision]], device=dev)
+        out = torch.empty((len(imgs), capi.PATCH, capi.PATCH, 3), dtype=torch.uint8, device=dev)
         sizes = sorted({int(i.shape[0]) for i in imgs})
         for P in sizes:
             sel = [k for k, i in enumerate(imgs) if int(i.shape[0]) == P]
@@ -52,9 +51,9 @@ def extract_features_from_pngs(patch_dir: str, net: capi.PackedResNet18, batch_s
             if P % 16:
                 raise capi.HipacError(f"patch size {P} is not a multiple of 16")
             xy = torch.stack([torch.zeros(m, dtype=torch.int32), torch.arange(m, dtype=torch.int32) * P], 1).to(dev)
-            o, _, _ = capi.tile_preprocess(stack.view(m * P, P, 3), xy, P, net.precision, want_sums=False)
+            o, _, _ = capi.tile_preprocess(stack.view(m * P, P, 3), xy, P, "u8", want_sums=False)
             out[torch.tensor(sel, device=dev)] = o
-        f, _, _ = net.forward(out, native_layout=True)
+        f, _, _ = net.forward(out)  # uint8 in: ToTensor/Normalize fused into the stem kernel
         feats.append(f.cpu())
         labels.extend(lbls.tolist())
         paths.extend(pths)

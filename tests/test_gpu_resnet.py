@@ -112,6 +112,23 @@ def test_native_layout_equals_nchw_path_bitwise():
     assert torch.equal(f1, f2) and torch.equal(l1, l2)
 
 
+def test_uint8_input_equals_normalize_then_forward_bitwise():
+    """in_layout = uint8 HWC (normalise fused into the stem) == patches_normalize -> native forward."""
+    sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
+    u8 = synth.synth_patches_u8(7, seed=21).cuda()
+    u8[0, :5] = 0
+    u8[1, :, -3:] = 255  # extreme values at the borders
+    for prec in ("bf16", "fp16"):
+        net = capi.PackedResNet18(sd, precision=prec)
+        f1, l1, lab1 = net.forward(capi.patches_normalize(u8, prec), want_logits=True, want_labels=True, native_layout=True)
+        pool1 = net.tap(7, 1).clone()
+        f2, l2, lab2 = net.forward(u8, want_logits=True, want_labels=True)
+        assert torch.equal(net.tap(7, 1), pool1)
+        assert torch.equal(f1, f2) and torch.equal(l1, l2) and torch.equal(lab1, lab2)
+    with pytest.raises(capi.HipacError):
+        net.forward(torch.zeros((2, 200, 224, 3), dtype=torch.uint8, device="cuda"))
+
+
 def test_sub_batching_and_determinism(monkeypatch):
     # internal schedule: early layers in sub-batches, late layers in groups.  Shrink both so
     # 131 patches = group 96 (sub-batches 48 + 48) + ragged group 35.
