@@ -127,13 +127,14 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
 
 /* Profiling aid: run ops first_op..last_op of the trunk (0 stem conv, 1 max-pool, then
  * per stage conv1(b0) [1x1 proj] conv2(b0) conv1(b1) conv2(b1); 21 ops) on the
- * activations a previous hipac_resnet18_forward(in_layout = NCHW) left in `workspace`.
+ * activations a previous hipac_resnet18_forward(x, in_layout) left in `workspace`
+ * (`x` is re-read by op 0 for the uint8 / native layouts).
  * Ops 0..10 (stem, pool, layer1, layer2) act on the first internal sub-batch
  * (min(batch, 512) images), ops 11..20 (layer3, layer4) on all `batch` images, which
  * must fit one internal group (4096).  Used by bench.py to time single kernels with
  * events on the caller's stream; not part of the reference's surface. */
-int hipac_resnet18_run_ops(const hipac_weights_t* w, void* workspace, size_t workspace_bytes, int batch,
-                           int first_op, int last_op, void* stream);
+int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layout, void* workspace,
+                           size_t workspace_bytes, int batch, int first_op, int last_op, void* stream);
 #define HIPAC_NUM_OPS 21
 
 /* Debug / test tap: copy one intermediate activation of the LAST forward run

@@ -61,7 +61,8 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
-    "hipac_resnet18_run_ops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hipac_resnet18_run_ops": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hipac_resnet18_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hipac_resample_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "hipac_tile_preprocess": (
@@ -283,11 +284,14 @@ class PackedResNet18:
         _check(rc, "hipac_resnet18_forward")
         return feats, logits, labels
 
-    def run_ops(self, batch: int, first: int, last: int):
-        """Re-run trunk ops first..last on the activations of the last forward (profiling aid)."""
+    def run_ops(self, x: torch.Tensor, first: int, last: int):
+        """Re-run trunk ops first..last on the activations the last forward(x) left behind
+        (profiling aid; x must be the same batch, it is re-read by op 0)."""
+        layout = IN_U8_HWC if x.dtype == torch.uint8 else (IN_NCHW_F32 if x.dtype == torch.float32 else IN_NHWC4_PAD)
         with torch.cuda.device(self._ws.device):
-            _check(self._lib.hipac_resnet18_run_ops(self.handle, self._ws.data_ptr(), self._ws.numel(), batch, first,
-                                                    last, _stream()), "hipac_resnet18_run_ops")
+            _check(self._lib.hipac_resnet18_run_ops(self.handle, x.data_ptr(), layout, self._ws.data_ptr(),
+                                                    self._ws.numel(), x.shape[0], first, last, _stream()),
+                   "hipac_resnet18_run_ops")
 
     def tap(self, batch: int, tap: int) -> torch.Tensor:
         """Intermediate activation of the last forward (float32 NCHW); tests only."""

@@ -385,20 +385,27 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   return 0;
 }
 
-int hipac_resnet18_run_ops(const hipac_weights_t* w, void* workspace, size_t workspace_bytes, int batch,
-                           int first_op, int last_op, void* stream) {
+int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layout, void* workspace,
+                           size_t workspace_bytes, int batch, int first_op, int last_op, void* stream) {
   HIPAC_REQUIRE(w && workspace, HIPAC_EINVAL, "run_ops: null argument");
-  const Plan p = make_plan(batch);
+  Plan p = make_plan(batch);
   HIPAC_REQUIRE(batch > 0 && batch <= p.gc, HIPAC_EINVAL, "run_ops: batch %d exceeds one group (%d)", batch, p.gc);
   HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "run_ops: workspace %zu < required %zu",
                 workspace_bytes, p.total);
   HIPAC_REQUIRE(first_op >= 0 && first_op <= last_op && last_op < kNumOps, HIPAC_EINVAL, "run_ops: range %d..%d",
                 first_op, last_op);
+  HIPAC_REQUIRE(in_layout == HIPAC_IN_NHWC4_PAD || in_layout == HIPAC_IN_U8_HWC || in_layout == HIPAC_IN_NCHW_F32,
+                HIPAC_EINVAL, "run_ops: in_layout %d", in_layout);
+  HIPAC_REQUIRE(first_op > 0 || x != nullptr || in_layout == HIPAC_IN_NCHW_F32, HIPAC_EINVAL,
+                "run_ops: op 0 needs the input batch");
   char* ws = (char*)workspace;
   auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
-  // early ops act on the first sub-batch, late ops on the whole group
+  // early ops act on the first sub-batch, late ops on the whole group; an NCHW input was
+  // converted into the workspace by the preceding forward
+  p.u8_input = in_layout == HIPAC_IN_U8_HWC && p.fuse_stem;
+  const void* xin = in_layout == HIPAC_IN_NCHW_F32 ? (const void*)(ws + p.xin) : x;
   const int ne = batch < p.bc ? batch : p.bc;
-  return trunk(w->net, p, ws, ws + p.xin, ne, 0, batch, (hipStream_t)stream, first_op, last_op);
+  return trunk(w->net, p, ws, xin, ne, 0, batch, (hipStream_t)stream, first_op, last_op);
 }
 
 int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap, float* dst,
