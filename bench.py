@@ -176,19 +176,15 @@ def run_wsi(args, rank, world, dev):
     stride_of = (lambda lvl: None) if args.grid == "reference" else (lambda lvl: extract.PATCH_SIZES[lvl])
 
     def step():
-        n_kept = n_all = 0
-        res = []
+        f, l, p, meta = extract.score_slide(slide, net, levels=(0, 1, 2, 3), batch_windows=args.batch_windows,
+                                            stride=stride_of)
+        n_all = 0
         for lvl in (0, 1, 2, 3):
-            f, l, p, meta = extract.score_slide(slide, net, levels=(lvl,), batch_windows=args.batch_windows,
-                                                stride=stride_of(lvl))
-            n_kept += f.shape[0]
             w, h = slide.level_dimensions[lvl]
             n_all += len(extract.window_grid(w, h, lvl, stride_of(lvl))[2])
-            res.append((f, l, meta))
         if world > 1:
-            for f, l, meta in res:
-                hdist.gather_results(f, l, meta)
-        return n_kept, n_all
+            hdist.gather_results(f, l, meta)
+        return f.shape[0], n_all
 
     for _ in range(args.warmup):
         step()
@@ -228,7 +224,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="patches per step per GPU")
     ap.add_argument("--slide_side", type=int, default=50000)
     ap.add_argument("--grid", choices=["reference", "nonoverlap"], default="reference")
-    ap.add_argument("--batch_windows", type=int, default=1024)
+    ap.add_argument("--batch_windows", type=int, default=4096)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 

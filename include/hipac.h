@@ -186,6 +186,35 @@ int hipac_tile_preprocess(const uint8_t* level, int W, int H, int64_t pitch, int
                           void* out, int out_format, uint32_t* sums, uint8_t* keep,
                           void* stream);
 
+/* ---- whole-level form ("planes") for windows on the reference's 224-pixel lattice ----
+ * With origins on multiples of 224 (src/main.py:682-683) and P = 224*s, s in {2,4,8}, every
+ * window's resampled pixels are a gather from ONE resampled image of the level, so each
+ * source pixel is read once per level instead of once per overlapping window (up to 64x at
+ * level 0).  Same arithmetic as hipac_tile_preprocess, bit for bit.
+ *   hipac_level_planes_sizes  : bytes of the three caller-owned scratch buffers
+ *   hipac_level_build_planes  : level (RGB, 3 B/px, 4-byte aligned base and pitch) -> himg, dimg,
+ *                               cells (sums of the 224x224 source cells, for the whiteness test)
+ *   hipac_level_window_stats  : per window sum of the padded PxPx3 pixels and keep flag
+ *                               (replaces np.mean(patch) > 240, src/main.py:718-720)
+ *   hipac_level_gather        : uint8[n,224,224,3] resized pixels of the listed windows
+ *                               (HIPAC_OUT_U8_HWC; feed to hipac_resnet18_forward as HIPAC_IN_U8_HWC)
+ * xy: int32[n,2] window origins, multiples of 224, x < W, y < H.  coeff_*: device tables as for
+ * hipac_tile_preprocess. */
+int hipac_level_planes_sizes(int W, int H, int P, size_t* himg_bytes, size_t* dimg_bytes, size_t* cell_bytes);
+int hipac_level_build_planes(const uint8_t* level, int W, int H, int64_t pitch, int P,
+                             const int32_t* coeff_bounds, const int32_t* coeff_kk, int ksize,
+                             void* himg, void* dimg, uint32_t* cells, void* stream);
+int hipac_level_window_stats(const uint32_t* cells, int W, int H, int P, const int32_t* xy, int n,
+                             uint32_t* sums, uint8_t* keep, void* stream);
+int hipac_level_gather(const void* dimg, int W, int H, int P, const int32_t* xy, int n, uint8_t* out,
+                       void* stream);
+
+/* Lattice form of hipac_window_labels (origins on multiples of 224): one pass over the mask
+ * into per-cell flags, then s x s cells per window.  Same result as hipac_window_labels. */
+int hipac_mask_cells(const uint8_t* mask, int W, int H, int64_t pitch, uint8_t* cellany, void* stream);
+int hipac_window_labels_cells(const uint8_t* cellany, int W, int H, int P, const int32_t* xy, int n,
+                              uint8_t* labels, void* stream);
+
 /* tumour / normal label per window: 1 iff any mask pixel > 0 inside
  * [x,x+P) x [y,y+P) (pixels outside the mask count as 0).
  * Replaces mask.crop(...) / np.any(... > 0), src/main.py:707-712. */

@@ -70,6 +70,17 @@ SYMBOLS = {
         [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
          C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "hipac_level_planes_sizes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                           C.POINTER(C.c_size_t)]),
+    "hipac_level_build_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hipac_level_window_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "hipac_level_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
+    "hipac_mask_cells": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "hipac_window_labels_cells": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p]),
     "hipac_window_labels": (
         C.c_int,
         [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
@@ -363,6 +374,57 @@ def tile_preprocess(
     return out, sums, keep
 
 
+class LevelPlanes:
+    """Whole-level resampling for windows on the 224-pixel lattice (P = 448 / 896 / 1792):
+    build once per level, then ``stats`` (sums, keep) and ``gather`` (uint8 patches) for any
+    list of lattice windows.  Bit-identical to ``tile_preprocess`` on the same windows."""
+
+    def __init__(self, level: torch.Tensor, P: int, width: Optional[int] = None):
+        _require_gpu(level)
+        if level.dtype != torch.uint8 or level.dim() != 3 or level.shape[2] != 3:
+            raise HipacError("level must be uint8[H,W,3]")
+        lib = load_library()
+        H, Wp, _ = level.shape
+        self.W, self.H, self.P = (Wp if width is None else int(width)), H, P
+        hb, db, cb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(lib.hipac_level_planes_sizes(self.W, self.H, P, C.byref(hb), C.byref(db), C.byref(cb)),
+               "hipac_level_planes_sizes")
+        dev = level.device
+        himg = torch.empty(hb.value, dtype=torch.uint8, device=dev)  # only needed while building
+        self.dimg = torch.empty(db.value, dtype=torch.uint8, device=dev)
+        self.cells = torch.empty(cb.value // 4, dtype=torch.int32, device=dev)
+        b, k, ksize = device_tables(P, dev)
+        with torch.cuda.device(dev):
+            rc = lib.hipac_level_build_planes(level.data_ptr(), self.W, self.H, Wp * 3, P, b.data_ptr(), k.data_ptr(),
+                                              ksize, himg.data_ptr(), self.dimg.data_ptr(), self.cells.data_ptr(),
+                                              _stream())
+        _check(rc, "hipac_level_build_planes")
+        self._lib, self.device = lib, dev
+        himg.record_stream(torch.cuda.current_stream(dev))
+        if os.environ.get("HIPAC_KEEP_HIMG"):
+            self.himg = himg  # debugging aid
+
+    def stats(self, xy: torch.Tensor):
+        n = xy.shape[0]
+        sums = torch.empty((n,), dtype=torch.int32, device=self.device)
+        keep = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self._lib.hipac_level_window_stats(self.cells.data_ptr(), self.W, self.H, self.P, xy.data_ptr(),
+                                                          n, sums.data_ptr(), keep.data_ptr(), _stream()),
+                       "hipac_level_window_stats")
+        return sums, keep
+
+    def gather(self, xy: torch.Tensor) -> torch.Tensor:
+        n = xy.shape[0]
+        out = torch.empty((n, PATCH, PATCH, 3), dtype=torch.uint8, device=self.device)
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self._lib.hipac_level_gather(self.dimg.data_ptr(), self.W, self.H, self.P, xy.data_ptr(), n,
+                                                    out.data_ptr(), _stream()), "hipac_level_gather")
+        return out
+
+
 def window_labels(mask: torch.Tensor, xy: torch.Tensor, P: int) -> torch.Tensor:
     """mask: uint8[H,W] on cuda; returns uint8[n] (1 = tumour)."""
     _require_gpu(mask, xy)
@@ -376,6 +438,26 @@ def window_labels(mask: torch.Tensor, xy: torch.Tensor, P: int) -> torch.Tensor:
     with torch.cuda.device(mask.device):
         rc = load_library().hipac_window_labels(mask.data_ptr(), W, H, W, xy.data_ptr(), n, P, labels.data_ptr(), _stream())
     _check(rc, "hipac_window_labels")
+    return labels
+
+
+def mask_cells(mask: torch.Tensor) -> torch.Tensor:
+    """uint8[H,W] mask -> uint8[ceil(H/224), ceil(W/224)] "any pixel > 0" flags."""
+    _require_gpu(mask)
+    H, W = mask.shape
+    out = torch.empty(((H + 223) // 224, (W + 223) // 224), dtype=torch.uint8, device=mask.device)
+    with torch.cuda.device(mask.device):
+        _check(load_library().hipac_mask_cells(mask.data_ptr(), W, H, W, out.data_ptr(), _stream()), "hipac_mask_cells")
+    return out
+
+
+def window_labels_cells(cellany: torch.Tensor, W: int, H: int, xy: torch.Tensor, P: int) -> torch.Tensor:
+    n = xy.shape[0]
+    labels = torch.empty((n,), dtype=torch.uint8, device=xy.device)
+    if n:
+        with torch.cuda.device(xy.device):
+            _check(load_library().hipac_window_labels_cells(cellany.data_ptr(), W, H, P, xy.data_ptr(), n,
+                                                            labels.data_ptr(), _stream()), "hipac_window_labels_cells")
     return labels
 
 

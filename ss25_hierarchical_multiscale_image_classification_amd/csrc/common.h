@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <type_traits>
+
 #include "../../include/hipac.h"
 
 namespace hipac {
@@ -33,6 +35,15 @@ template <> struct Elem<_Float16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 
 // Fixed ResNet18@224 geometry.
 constexpr int kPatch = HIPAC_PATCH;

@@ -23,15 +23,6 @@
 
 namespace hipac {
 
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BN, bool RELU,
           bool RESID, bool OUTF32, bool STEM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ in,

@@ -1,0 +1,454 @@
+// Level resampler ("planes"): the whole-level form of the tile preprocess for windows on
+// the reference's 224-pixel lattice (src/main.py:682-683: x, y in range(0, ..., 224)).
+//
+// With window size P = 224*s (s = 2, 4, 8) and origins on multiples of 224, column j of a
+// window at x = 224*i resamples source columns that depend only on the GLOBAL output column
+// g = (224/s)*i + j -- except j = 0 and j = 223, whose Pillow kernels are clamped to the
+// window and therefore depend on i.  The same holds for rows.  So instead of resampling each
+// window on its own (each level-0 pixel up to 64 times at stride 224) the level is resampled
+// ONCE into an image D of (GY + 2*NY) rows x (G + 2*NX) columns:
+//     columns [0, G)            interior kernel at global column g
+//     columns [G, G+NX)         left-edge kernel (j = 0) of window column i
+//     columns [G+NX, G+2NX)     right-edge kernel (j = 223) of window column i
+// and likewise for rows; a window is then a gather from D.  Arithmetic is Pillow's two-pass
+// 8bpc resampler exactly (horizontal pass, uint8, vertical pass, uint8; 22-bit weights): the
+// interior weights are (2t+1) * 2^22 / (2 s^2) exactly, so the interior accumulation is the
+// small-integer dot product (s^2 + sum w_t p_t) >> log2(2 s^2), done with v_dot4_u32_u8.
+// The 224x224 "cell" sums needed for the whiteness test (a window = s x s cells) fall out of
+// the same pass over the source.  Pixels are kept as RGBX dwords in the H and D images.
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+
+namespace hipac {
+
+constexpr int kLat = 224;  // window lattice and output size
+
+struct PlaneGeom {
+  int s, ng;          // scale, 224/s
+  int NX, NY;         // window columns / rows on the lattice (origins < W, < H)
+  int G, GY;          // dense output columns / rows
+  int HW;             // H/D image row length in pixels = G + 2*NX
+  int HROWS;          // source rows covered by the horizontal pass = 224*(NY-1) + P
+  int DROWS;          // D image rows = GY + 2*NY
+  int NGRP;           // 8-pixel source groups per row = (224*(NX-1) + P) / 8
+  int NCX, NCY;       // cell grid
+};
+
+static PlaneGeom make_geom(int W, int H, int P) {
+  PlaneGeom g;
+  g.s = P / kLat;
+  g.ng = kLat / g.s;
+  g.NX = (W + kLat - 1) / kLat;
+  g.NY = (H + kLat - 1) / kLat;
+  g.G = g.ng * (g.NX - 1) + kLat;
+  g.GY = g.ng * (g.NY - 1) + kLat;
+  g.HW = g.G + 2 * g.NX;
+  g.HROWS = kLat * (g.NY - 1) + P;
+  g.DROWS = g.GY + 2 * g.NY;
+  g.NGRP = (kLat * (g.NX - 1) + P) / 8;
+  g.NCX = g.NX + g.s - 1;
+  g.NCY = g.NY + g.s - 1;
+  return g;
+}
+
+// Pillow's clip8 of a 22-bit fixed-point accumulator.  The empty asm keeps hipcc (ROCm 7.2)
+// from fusing two neighbouring clamps into gfx950's v_ashr_pk_u8_i32: that instruction leaves
+// non-zero bits above bit 15 of its result, which the surrounding `| (b << 16)` then picks up
+// (observed: a wrong blue channel; reproduced in isolation).
+__device__ __forceinline__ unsigned clip8p(int acc) {
+  int v = acc >> 22;
+  v = v < 0 ? 0 : v;
+  v = v > 255 ? 255 : v;
+  asm volatile("" : "+v"(v));
+  return (unsigned)v;
+}
+
+// weight dword for the interior kernel: bytes of cover dword `dw` (cover starts CB0 bytes
+// before the group's first byte), channel ch, output k of the group
+template <int S>
+__host__ __device__ constexpr unsigned interior_wdword(int k, int ch, int dw) {
+  constexpr int CB0 = S == 8 ? 12 : (S == 4 ? 8 : 4);
+  unsigned w = 0;
+  for (int b = 0; b < 4; ++b) {
+    const int byte = dw * 4 + b - CB0;            // relative to the group's first byte (pixel 8h)
+    const int px = byte >= 0 ? byte / 3 : -((-byte + 2) / 3);  // floor(byte / 3)
+    const int c = byte - px * 3;
+    const int t = px - (S * k - S / 2);           // tap index of output k (taps start at 8h + S*k - S/2)
+    if (c == ch && t >= 0 && t < 2 * S) {
+      const int wt = t < S ? 2 * t + 1 : 4 * S - 1 - 2 * t;
+      w |= (unsigned)wt << (8 * b);
+    }
+  }
+  return w;
+}
+
+// byte `bo` of the cover (compile-time offset)
+template <int BO, int NDW>
+__device__ __forceinline__ int cover_byte(const unsigned (&d)[NDW]) {
+  static_assert(BO >= 0 && BO < 4 * NDW, "inside the cover");
+  return (int)((d[BO / 4] >> (8 * (BO % 4))) & 255u);
+}
+
+// Pillow's clamped kernel for window column 0 / 223: 3S/2 taps starting P0 pixels after the
+// group's first pixel, general 22-bit weights kt[0..3S/2)
+template <int S, int P0, int NDW>
+__device__ __forceinline__ unsigned edge_pixel(const unsigned (&d)[NDW], const int* __restrict__ kt) {
+  constexpr int CB0 = S == 8 ? 12 : (S == 4 ? 8 : 4);
+  constexpr int ECNT = 3 * S / 2;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+  static_for<ECNT>([&](auto TT) {
+    constexpr int t = decltype(TT)::value;
+    constexpr int bo = CB0 + 3 * (P0 + t);
+    const int kv = kt[t];
+    a0 += cover_byte<bo>(d) * kv;
+    a1 += cover_byte<bo + 1>(d) * kv;
+    a2 += cover_byte<bo + 2>(d) * kv;
+  });
+  return clip8p(a0) | (clip8p(a1) << 8) | (clip8p(a2) << 16) | 0xff000000u;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: horizontal pass.  thread = one group of 8 source pixels (24 bytes) x a strip of 16 rows.
+// ---------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void hpass_kernel(const uint8_t* __restrict__ level, int W, int H,
+                                                    long long pitch, PlaneGeom gm,
+                                                    const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                    int ksize, unsigned* __restrict__ himg,
+                                                    unsigned* __restrict__ cells) {
+  constexpr int CB0 = S == 8 ? 12 : (S == 4 ? 8 : 4);   // cover start, bytes before the group
+  constexpr int NDW = S == 8 ? 12 : (S == 4 ? 10 : 8);  // cover length in dwords
+  constexpr int NOUT = 8 / S;                           // dense outputs per group
+  constexpr int LOG2 = S == 8 ? 7 : (S == 4 ? 5 : 3);   // log2(2 S^2)
+  constexpr int RS = 16;                                // rows per strip (divides 224)
+  constexpr int GPC = kLat / 8;                         // groups per cell = 28
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = h < gm.NGRP;
+  const int r0 = blockIdx.y * RS;
+  const long long cb = 24LL * h - CB0;
+  const long long wbytes = 3LL * W;
+  // window-edge duties of this group
+  const int hm = h % GPC;
+  const int win_i = h / GPC;
+  const bool is_left = live && hm == 0 && win_i < gm.NX;
+  // right edge of window i ends at pixel 224 i + P: group index 28 i + P/8 - 1
+  const int hr = h - (S * kLat / 8 - 1);
+  const bool is_right = live && hr >= 0 && hr % GPC == 0 && hr / GPC < gm.NX;
+  const int right_i = hr / GPC;
+  unsigned gsum = 0;
+  for (int rr = 0; rr < RS; ++rr) {
+    const int y = r0 + rr;
+    if (y >= gm.HROWS) break;
+    unsigned d[NDW];
+    const bool row_ok = y < H;
+    const uint8_t* rowp = level + (long long)y * pitch;
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) {
+      const long long o = cb + 4 * k;
+      unsigned v = 0xffffffffu;
+      if (live && row_ok && o >= 0 && o + 4 <= pitch) {
+        v = *reinterpret_cast<const unsigned*>(rowp + o);
+        const long long nv = wbytes - o;  // valid bytes in this dword
+        if (nv < 4) v |= nv <= 0 ? 0xffffffffu : (0xffffffffu << (8 * (int)nv));
+      }
+      d[k] = v;
+    }
+    if (live) {
+      // whiteness: bytes [24h, 24h+24) = cover dwords CB0/4 .. CB0/4+5
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gsum = __builtin_amdgcn_sad_u8(d[CB0 / 4 + k], 0u, gsum);
+      // dense interior outputs (weight dwords are compile-time constants; zero ones vanish)
+      unsigned* hrow = himg + (long long)y * gm.HW;
+      static_for<NOUT>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        unsigned px = 0xff000000u;
+        static_for<3>([&](auto CH) {
+          constexpr int ch = decltype(CH)::value;
+          unsigned x = 0;
+          static_for<NDW>([&](auto DW) {
+            constexpr int dw = decltype(DW)::value;
+            constexpr unsigned wt = interior_wdword<S>(k, ch, dw);
+            if constexpr (wt != 0) x = __builtin_amdgcn_udot4(d[dw], wt, x, false);
+          });
+          px |= ((S * S + x) >> LOG2) << (8 * ch);
+        });
+        hrow[h * NOUT + k] = px;
+      });
+      // sparse edge outputs: Pillow's clamped kernels for window columns 0 and 223 (general
+      // 22-bit weights from the table; tap positions are fixed by S: 3S/2 taps at the window's
+      // first / last pixels), bytes extracted from the cover at compile-time offsets
+      if (is_left) hrow[gm.G + win_i] = edge_pixel<S, 0>(d, kk);
+      if (is_right) hrow[gm.G + gm.NX + right_i] = edge_pixel<S, 8 - 3 * S / 2>(d, kk + 223 * ksize);
+    }
+  }
+  // cell sums: segmented reduction over the lanes of a wave that share a cell column
+  const int cx = live ? h / GPC : -1 - lane;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(gsum, off, 64);
+    const int cup = __shfl_up(cx, off, 64);
+    if (lane >= off && cup == cx) gsum += up;
+  }
+  const int cnext = __shfl_down(cx, 1, 64);
+  if (live && (lane == 63 || cnext != cx)) atomicAdd(&cells[(r0 / kLat) * gm.NCX + cx], gsum);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: vertical pass over the H image.  thread = one D pixel.
+// ---------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void vpass_kernel(const unsigned* __restrict__ himg, PlaneGeom gm,
+                                                    const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                    int ksize, unsigned* __restrict__ dimg) {
+  constexpr int LOG2 = S == 8 ? 7 : (S == 4 ? 5 : 3);
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int rr = blockIdx.y;
+  if (col >= gm.HW) return;
+  unsigned out;
+  if (rr < gm.GY) {
+    const int row0 = S * rr - S / 2;
+    if (row0 < 0 || row0 + 2 * S > gm.HROWS) {
+      out = 0xff000000u;  // first / last dense row: never used (rows 0 and 223 of a window are edge rows)
+    } else {
+      unsigned rb = 0, g = 0;  // R and B accumulate in 16-bit lanes of one dword (max 255 * 2 S^2 < 65536)
+#pragma unroll
+      for (int t = 0; t < 2 * S; ++t) {
+        const unsigned wt = t < S ? 2 * t + 1 : 4 * S - 1 - 2 * t;
+        const unsigned px = himg[(long long)(row0 + t) * gm.HW + col];
+        rb += (px & 0x00ff00ffu) * wt;
+        g += ((px >> 8) & 0xffu) * wt;
+      }
+      const unsigned r = ((rb & 0xffffu) + S * S) >> LOG2;
+      const unsigned b = ((rb >> 16) + S * S) >> LOG2;
+      const unsigned gg = (g + S * S) >> LOG2;
+      out = r | (gg << 8) | (b << 16) | 0xff000000u;
+    }
+  } else {
+    const bool top = rr < gm.GY + gm.NY;
+    const int iy = top ? rr - gm.GY : rr - gm.GY - gm.NY;
+    const int j = top ? 0 : 223;
+    const int row0 = kLat * iy + bounds[2 * j], cnt = bounds[2 * j + 1];
+    const int* k = kk + j * ksize;
+    int a0 = 1 << 21, a1 = a0, a2 = a0;
+    for (int t = 0; t < cnt; ++t) {
+      const unsigned px = himg[(long long)(row0 + t) * gm.HW + col];
+      const int kv = k[t];
+      a0 += (int)(px & 255u) * kv;
+      a1 += (int)((px >> 8) & 255u) * kv;
+      a2 += (int)((px >> 16) & 255u) * kv;
+    }
+    out = clip8p(a0) | (clip8p(a1) << 8) | (clip8p(a2) << 16) | 0xff000000u;
+  }
+  dimg[(long long)rr * gm.HW + col] = out;
+}
+
+// K3: window sums from cell sums; keep = sum <= 240*3*P*P
+__global__ void window_stats_kernel(const unsigned* __restrict__ cells, PlaneGeom gm, const int* __restrict__ xy,
+                                    int n, unsigned* __restrict__ sums, unsigned char* __restrict__ keep,
+                                    unsigned threshold) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int i = xy[2 * w] / kLat, iy = xy[2 * w + 1] / kLat;
+  unsigned s = 0;
+  for (int a = 0; a < gm.s; ++a)
+    for (int b = 0; b < gm.s; ++b) s += cells[(iy + a) * gm.NCX + i + b];
+  if (sums) sums[w] = s;
+  if (keep) keep[w] = s <= threshold ? 1 : 0;
+}
+
+// K4: gather windows from D.  block = (row strip of 8, window); thread item = 4 output pixels.
+__global__ __launch_bounds__(256) void gather_kernel(const unsigned* __restrict__ dimg, PlaneGeom gm,
+                                                     const int* __restrict__ xy, unsigned char* __restrict__ out) {
+  const int w = blockIdx.y;
+  const int i = xy[2 * w] / kLat, iy = xy[2 * w + 1] / kLat;
+  const int gx0 = gm.ng * i, gy0 = gm.ng * iy;
+  for (int item = threadIdx.x; item < 8 * 56; item += 256) {
+    const int jy = blockIdx.x * 8 + item / 56, q = item % 56;
+    const int rr = jy == 0 ? gm.GY + iy : (jy == 223 ? gm.GY + gm.NY + iy : gy0 + jy);
+    const unsigned* drow = dimg + (long long)rr * gm.HW;
+    unsigned p[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int jx = 4 * q + e;
+      const int cc = jx == 0 ? gm.G + i : (jx == 223 ? gm.G + gm.NX + i : gx0 + jx);
+      p[e] = drow[cc];
+    }
+    // 4 RGBX pixels -> 12 bytes RGBRGBRGBRGB
+    const unsigned o0 = (p[0] & 0x00ffffffu) | (p[1] << 24);
+    const unsigned o1 = ((p[1] >> 8) & 0x0000ffffu) | (p[2] << 16);
+    const unsigned o2 = ((p[2] >> 16) & 0x000000ffu) | (p[3] << 8);
+    unsigned* dst = reinterpret_cast<unsigned*>(out + ((size_t)w * kLat + jy) * (kLat * 3) + q * 12);
+    dst[0] = o0;
+    dst[1] = o1;
+    dst[2] = o2;
+  }
+}
+
+// mask -> per-cell "any pixel > 0" flags (cells of 224 x 224, zero outside the mask).
+// block = one cell row of 16 mask rows x 4 cells... simple form: one workgroup per cell.
+__global__ __launch_bounds__(256) void mask_cells_kernel(const uint8_t* __restrict__ mask, int W, int H,
+                                                         long long pitch, int ncx, unsigned char* __restrict__ cellany) {
+  __shared__ int any_s;
+  const int cx = blockIdx.x, cy = blockIdx.y, tid = threadIdx.x;
+  if (tid == 0) any_s = 0;
+  __syncthreads();
+  const int x0 = cx * kLat, y0 = cy * kLat;
+  const int cols = min(kLat, W - x0), rows = min(kLat, H - y0);
+  int found = 0;
+  if (cols > 0 && rows > 0) {
+    for (int i = tid; i < rows * cols && !found; i += 256) {
+      const int ry = i / cols, rx = i - ry * cols;
+      if (mask[(long long)(y0 + ry) * pitch + x0 + rx] > 0) found = 1;
+    }
+  }
+  if (found) atomicOr(&any_s, 1);
+  __syncthreads();
+  if (tid == 0) cellany[cy * ncx + cx] = (unsigned char)any_s;
+}
+
+__global__ void window_labels_cells_kernel(const unsigned char* __restrict__ cellany, int ncx, int ncy, int s,
+                                           const int* __restrict__ xy, int n, unsigned char* __restrict__ labels) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int i = xy[2 * w] / kLat, iy = xy[2 * w + 1] / kLat;
+  unsigned char any = 0;
+  for (int a = 0; a < s; ++a)
+    for (int b = 0; b < s; ++b)
+      if (iy + a < ncy && i + b < ncx) any |= cellany[(iy + a) * ncx + i + b];
+  labels[w] = any ? 1 : 0;
+}
+
+}  // namespace hipac
+
+using namespace hipac;
+
+extern "C" {
+
+static int check_planes_args(int W, int H, int P) {
+  HIPAC_REQUIRE(W > 0 && H > 0, HIPAC_EINVAL, "level planes: bad geometry");
+  HIPAC_REQUIRE(P == 448 || P == 896 || P == 1792, HIPAC_EINVAL, "level planes: P %d (448, 896 or 1792)", P);
+  return 0;
+}
+
+int hipac_level_planes_sizes(int W, int H, int P, size_t* himg_bytes, size_t* dimg_bytes, size_t* cell_bytes) {
+  int rc = check_planes_args(W, H, P);
+  if (rc) return rc;
+  const PlaneGeom g = make_geom(W, H, P);
+  if (himg_bytes) *himg_bytes = (size_t)g.HROWS * g.HW * 4;
+  if (dimg_bytes) *dimg_bytes = (size_t)g.DROWS * g.HW * 4;
+  if (cell_bytes) *cell_bytes = (size_t)g.NCX * g.NCY * 4;
+  return 0;
+}
+
+int hipac_level_build_planes(const uint8_t* level, int W, int H, int64_t pitch, int P, const int32_t* coeff_bounds,
+                             const int32_t* coeff_kk, int ksize, void* himg, void* dimg, uint32_t* cells,
+                             void* stream) {
+  int rc = check_planes_args(W, H, P);
+  if (rc) return rc;
+  HIPAC_REQUIRE(level && coeff_bounds && coeff_kk && himg && dimg && cells, HIPAC_EINVAL,
+                "level_build_planes: null argument");
+  HIPAC_REQUIRE(pitch >= (int64_t)W * 3 && pitch % 4 == 0 && ((uintptr_t)level & 3) == 0, HIPAC_EINVAL,
+                "level_build_planes: level base and pitch must be 4-byte aligned (RGB, 3 bytes per pixel)");
+  const PlaneGeom g = make_geom(W, H, P);
+  HIPAC_REQUIRE(ksize == 2 * g.s + 1, HIPAC_EINVAL, "level_build_planes: ksize %d != %d", ksize, 2 * g.s + 1);
+  {
+    // the kernels hard-wire Pillow's tap geometry for integer scales; re-derive it on the host and refuse
+    // to run if it ever differs (bounds of columns 0, 1 and 223)
+    std::vector<int32_t> b(2 * 224), k((size_t)224 * ksize);
+    HIPAC_REQUIRE(hipac_resample_coeffs(P, 224, b.data(), k.data(), ksize) == ksize, HIPAC_EINVAL,
+                  "level_build_planes: coefficient table");
+    const int s_ = g.s;
+    bool ok = b[0] == 0 && b[1] == 3 * s_ / 2 && b[2 * 223] == P - 3 * s_ / 2 && b[2 * 223 + 1] == 3 * s_ / 2;
+    for (int j = 1; j < 223 && ok; ++j) {
+      ok = b[2 * j] == s_ * j - s_ / 2 && b[2 * j + 1] == 2 * s_;
+      for (int t = 0; t < 2 * s_ && ok; ++t) {
+        const int wt = t < s_ ? 2 * t + 1 : 4 * s_ - 1 - 2 * t;
+        ok = k[(size_t)j * ksize + t] == wt * ((1 << 22) / (2 * s_ * s_));
+      }
+    }
+    HIPAC_REQUIRE(ok, HIPAC_EUNSUPPORTED, "level_build_planes: resampling table does not have the expected structure");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  HIPAC_CHECK_HIP(hipMemsetAsync(cells, 0, (size_t)g.NCX * g.NCY * 4, s));
+  dim3 g1((g.NGRP + 255) / 256, (g.HROWS + 15) / 16);
+  dim3 g2((g.HW + 255) / 256, g.DROWS);
+  unsigned* hi = (unsigned*)himg;
+  unsigned* di = (unsigned*)dimg;
+  switch (g.s) {
+    case 8:
+      hipLaunchKernelGGL((hpass_kernel<8>), g1, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds,
+                         coeff_kk, ksize, hi, cells);
+      hipLaunchKernelGGL((vpass_kernel<8>), g2, dim3(256), 0, s, hi, g, coeff_bounds, coeff_kk, ksize, di);
+      break;
+    case 4:
+      hipLaunchKernelGGL((hpass_kernel<4>), g1, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds,
+                         coeff_kk, ksize, hi, cells);
+      hipLaunchKernelGGL((vpass_kernel<4>), g2, dim3(256), 0, s, hi, g, coeff_bounds, coeff_kk, ksize, di);
+      break;
+    default:
+      hipLaunchKernelGGL((hpass_kernel<2>), g1, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds,
+                         coeff_kk, ksize, hi, cells);
+      hipLaunchKernelGGL((vpass_kernel<2>), g2, dim3(256), 0, s, hi, g, coeff_bounds, coeff_kk, ksize, di);
+  }
+  HIPAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipac_level_window_stats(const uint32_t* cells, int W, int H, int P, const int32_t* xy, int n, uint32_t* sums,
+                             uint8_t* keep, void* stream) {
+  int rc = check_planes_args(W, H, P);
+  if (rc) return rc;
+  HIPAC_REQUIRE(cells && xy && n >= 0, HIPAC_EINVAL, "level_window_stats: bad argument");
+  if (n == 0) return 0;
+  const PlaneGeom g = make_geom(W, H, P);
+  const unsigned thr = 240u * 3u * (unsigned)P * (unsigned)P;
+  hipLaunchKernelGGL(window_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cells, g, xy, n,
+                     sums, keep, thr);
+  HIPAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipac_level_gather(const void* dimg, int W, int H, int P, const int32_t* xy, int n, uint8_t* out,
+                       void* stream) {
+  int rc = check_planes_args(W, H, P);
+  if (rc) return rc;
+  HIPAC_REQUIRE(dimg && xy && out && n >= 0, HIPAC_EINVAL, "level_gather: bad argument");
+  if (n == 0) return 0;
+  const PlaneGeom g = make_geom(W, H, P);
+  hipLaunchKernelGGL(gather_kernel, dim3(kLat / 8, n), dim3(256), 0, (hipStream_t)stream, (const unsigned*)dimg, g,
+                     xy, out);
+  HIPAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+/* Cell form of hipac_window_labels for lattice windows: one pass over the mask, then s x s
+ * cell flags per window.  cellany: uint8[ceil(H/224)][ceil(W/224)] (caller-owned). */
+int hipac_mask_cells(const uint8_t* mask, int W, int H, int64_t pitch, uint8_t* cellany, void* stream) {
+  HIPAC_REQUIRE(mask && cellany && W > 0 && H > 0 && pitch >= W, HIPAC_EINVAL, "mask_cells: bad argument");
+  const int ncx = (W + kLat - 1) / kLat, ncy = (H + kLat - 1) / kLat;
+  hipLaunchKernelGGL(mask_cells_kernel, dim3(ncx, ncy), dim3(256), 0, (hipStream_t)stream, mask, W, H,
+                     (long long)pitch, ncx, cellany);
+  HIPAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipac_window_labels_cells(const uint8_t* cellany, int W, int H, int P, const int32_t* xy, int n,
+                              uint8_t* labels, void* stream) {
+  HIPAC_REQUIRE(cellany && xy && labels && n >= 0 && W > 0 && H > 0, HIPAC_EINVAL, "window_labels_cells: bad argument");
+  HIPAC_REQUIRE(P >= kLat && P % kLat == 0, HIPAC_EINVAL, "window_labels_cells: P %d", P);
+  if (n == 0) return 0;
+  const int ncx = (W + kLat - 1) / kLat, ncy = (H + kLat - 1) / kLat;
+  hipLaunchKernelGGL(window_labels_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cellany,
+                     ncx, ncy, P / kLat, xy, n, labels);
+  HIPAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

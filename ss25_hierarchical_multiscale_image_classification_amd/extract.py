@@ -143,14 +143,34 @@ class LevelScan:
 
 
 def iter_level(slide: DeviceSlide, level: int, out_format: str = "bf16", batch_windows: int = 512,
-               stride: Optional[int] = None, pad: bool = True, kept_only: bool = True) -> Iterator[dict]:
+               stride: Optional[int] = None, pad: bool = True, kept_only: bool = True,
+               use_planes: Optional[bool] = None) -> Iterator[dict]:
     """Stream one level: for each batch of windows run the preprocess kernel and yield
     {"x": network input (kept windows only when ``kept_only``), "xy", "sums", "keep",
-    "labels"} -- all device tensors."""
+    "labels"} -- all device tensors.
+
+    ``use_planes`` (default: whenever it applies, i.e. uint8 output, P > 224 and a stride that is
+    a multiple of 224) resamples the level once (``capi.LevelPlanes``) and gathers windows from
+    it instead of resampling every overlapping window separately; results are identical."""
     width, height = slide.level_dimensions[level]
-    P, _, xy_np = window_grid(width, height, level, stride, pad)
+    P, eff_stride, xy_np = window_grid(width, height, level, stride, pad)
     img = slide.levels[level]
     mask = slide.mask(level)
+    can_planes = out_format == "u8" and P in (448, 896, 1792) and eff_stride % 224 == 0
+    if use_planes is None:
+        use_planes = can_planes
+    if use_planes and not can_planes:
+        raise capi.HipacError("planes path needs uint8 output, P in (448, 896, 1792) and a stride multiple of 224")
+    if use_planes:
+        planes = capi.LevelPlanes(img, P, width=width)
+        for i0 in range(0, len(xy_np), batch_windows):
+            xy = torch.from_numpy(xy_np[i0 : i0 + batch_windows]).to(slide.device)
+            sums, keep = planes.stats(xy)
+            labels = (capi.window_labels(mask, xy, P) if mask is not None
+                      else torch.zeros((xy.shape[0],), dtype=torch.uint8, device=slide.device))
+            sel = xy.index_select(0, torch.nonzero(keep, as_tuple=False).flatten()) if kept_only else xy
+            yield {"x": planes.gather(sel), "xy": xy, "sums": sums, "keep": keep, "labels": labels}
+        return
     for i0 in range(0, len(xy_np), batch_windows):
         xy = torch.from_numpy(xy_np[i0 : i0 + batch_windows]).to(slide.device)
         out, sums, keep = capi.tile_preprocess(img, xy, P, out_format, width=width)
@@ -173,47 +193,111 @@ def scan_level(slide: DeviceSlide, level: int, **kw) -> LevelScan:
     return LevelScan(level, P, cat("xy"), cat("sums"), cat("keep"), cat("labels"))
 
 
+class LevelWindows:
+    """All extractor decisions of one level at once (device tensors, reference visiting
+    order): window origins, whiteness sums, keep flags, tumour labels -- plus the resized
+    uint8 pixels of any subset of windows on demand."""
+
+    def __init__(self, slide: DeviceSlide, level: int, stride: Optional[int] = None, pad: bool = True,
+                 use_planes: Optional[bool] = None):
+        self.level = level
+        width, height = slide.level_dimensions[level]
+        self.P, eff_stride, xy_np = window_grid(width, height, level, stride, pad)
+        self.width, self.height = width, height
+        self.img = slide.levels[level]
+        self.xy = torch.from_numpy(xy_np).to(slide.device)
+        on_lattice = eff_stride % 224 == 0
+        can_planes = self.P in (448, 896, 1792) and on_lattice
+        self.planes = capi.LevelPlanes(self.img, self.P, width=width) if (can_planes and use_planes is not False) else None
+        if use_planes and not can_planes:
+            raise capi.HipacError("planes path needs P in (448, 896, 1792) and a stride multiple of 224")
+        self._all_u8 = None
+        if self.planes is not None:
+            self.sums, self.keep = self.planes.stats(self.xy)
+        else:
+            self._all_u8, self.sums, self.keep = capi.tile_preprocess(self.img, self.xy, self.P, "u8", width=width)
+        mask = slide.mask(level)
+        if mask is None:
+            self.labels = torch.zeros((self.xy.shape[0],), dtype=torch.uint8, device=slide.device)
+        elif on_lattice:
+            self.labels = capi.window_labels_cells(capi.mask_cells(mask), width, height, self.xy, self.P)
+        else:
+            self.labels = capi.window_labels(mask, self.xy, self.P)
+
+    def kept_index(self) -> torch.Tensor:
+        return torch.nonzero(self.keep, as_tuple=False).flatten()
+
+    def patches(self, idx: torch.Tensor) -> torch.Tensor:
+        """uint8[len(idx),224,224,3] resized pixels of the selected windows."""
+        if self._all_u8 is not None:
+            return self._all_u8.index_select(0, idx)
+        return self.planes.gather(self.xy.index_select(0, idx))
+
+    def meta(self, idx: torch.Tensor) -> torch.Tensor:
+        xy = self.xy.index_select(0, idx)
+        lab = self.labels.index_select(0, idx).to(torch.int32)
+        return torch.cat([torch.full_like(lab, self.level)[:, None], xy, lab[:, None]], dim=1)
+
+
 class WSIPatchStream:
     """Iterable over (x, meta) device batches of KEPT windows for the fused path:
     x = the resized uint8[B,224,224,3] pixels (the network's stem applies
     ToTensor/Normalize itself), meta int32[B,4] = (level, x, y, label)."""
 
-    def __init__(self, slide: DeviceSlide, levels: Sequence[int] = (0, 1, 2, 3), batch_windows: int = 512,
+    def __init__(self, slide: DeviceSlide, levels: Sequence[int] = (0, 1, 2, 3), batch_windows: int = 4096,
                  precision: str = "bf16", stride: Optional[int] = None):
         self.slide, self.levels, self.batch_windows = slide, tuple(levels), batch_windows
         self.precision, self.stride = precision, stride
 
     def __iter__(self):
         for level in self.levels:
-            for part in iter_level(self.slide, level, out_format="u8", batch_windows=self.batch_windows,
-                                   stride=self.stride):
-                idx = torch.nonzero(part["keep"], as_tuple=False).flatten()
-                xy = part["xy"].index_select(0, idx)
-                lab = part["labels"].index_select(0, idx).to(torch.int32)
-                meta = torch.cat([torch.full_like(lab, level)[:, None], xy, lab[:, None]], dim=1)
-                yield part["x"], meta
+            stride = self.stride(level) if callable(self.stride) else self.stride
+            lw = LevelWindows(self.slide, level, stride)
+            kept = lw.kept_index()
+            for i0 in range(0, kept.shape[0], self.batch_windows):
+                idx = kept[i0 : i0 + self.batch_windows]
+                yield lw.patches(idx), lw.meta(idx)
 
 
 @torch.no_grad()
 def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[int] = (0, 1, 2, 3),
-                batch_windows: int = 512, stride: Optional[int] = None, want_logits: bool = True):
-    """Whole-slide hierarchical scan: windows -> preprocess -> ResNet18 -> per-patch
-    features / logits / labels.  Returns device tensors (feats[n,512], logits[n,C] or
-    None, pred int64[n] or None, meta int32[n,4])."""
-    feats, logits, preds, metas = [], [], [], []
+                batch_windows: int = 4096, stride=None, want_logits: bool = True):
+    """Whole-slide hierarchical scan: windows -> whiteness/labels -> resize -> ResNet18 ->
+    per-patch features / logits / labels.  The kept windows of ALL requested levels are scored
+    in large batches (the late ResNet layers need thousands of patches per launch to fill the
+    chip).  ``stride``: None (reference: 224), an int, or a callable level -> stride.
+    Returns device tensors (feats[n,512], logits[n,C] or None, pred int64[n] or None,
+    meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order."""
     has_fc = net.num_classes > 0 and want_logits
+    xs, metas = [], []
     for x, meta in WSIPatchStream(slide, levels, batch_windows, net.precision, stride):
-        if x.shape[0] == 0:
-            continue
-        f, l, p = net.forward(x, want_feats=True, want_logits=has_fc, want_labels=has_fc)
+        if x.shape[0]:
+            xs.append(x)
+            metas.append(meta)
+    dev = slide.device
+    if not xs:
+        return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
+    feats, logits, preds = [], [], []
+    pend, pend_n = [], 0
+
+    def flush():
+        nonlocal pend, pend_n
+        if not pend:
+            return
+        xb = torch.cat(pend) if len(pend) > 1 else pend[0]
+        f, l, p = net.forward(xb, want_feats=True, want_logits=has_fc, want_labels=has_fc)
         feats.append(f)
-        metas.append(meta)
         if has_fc:
             logits.append(l)
             preds.append(p)
-    dev = slide.device
-    if not feats:
-        return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
+        pend, pend_n = [], 0
+
+    for x in xs:
+        pend.append(x)
+        pend_n += x.shape[0]
+        if pend_n >= 8192:
+            flush()
+    flush()
     return (torch.cat(feats), torch.cat(logits) if has_fc else None, torch.cat(preds) if has_fc else None,
             torch.cat(metas))
 

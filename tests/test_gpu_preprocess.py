@@ -139,3 +139,44 @@ def test_empty_and_properties_at_scale():
         nx, ny = -(-w // P), -(-h // P)
         pad_px = nx * P * ny * P - w * h
         assert total == img_sum + 255 * 3 * pad_px
+
+
+@pytest.mark.parametrize("P", [448, 896, 1792])
+def test_level_planes_equal_per_window_kernel(P):
+    """The whole-level resampler (each source pixel read once) == the per-window kernel, bit for
+    bit: resized pixels, sums and keep flags, on noise (worst case for rounding) with ragged
+    right/bottom edges, for every window of the reference's stride-224 grid."""
+    rng = np.random.RandomState(P)
+    H, W = 2 * P + 300, 2 * P + 77
+    img = torch.from_numpy(rng.randint(0, 256, (H, W, 3), dtype=np.uint8))
+    img[: P // 2, : P // 2] = 252  # a near-white corner so some windows are dropped
+    s = extract.DeviceSlide([img], device="cuda")
+    xs = np.arange(0, W, 224)
+    ys = np.arange(0, H, 224)
+    xy = torch.from_numpy(np.stack([np.repeat(xs, len(ys)), np.tile(ys, len(xs))], 1).astype(np.int32)).cuda()
+    ref_u8, ref_sums, ref_keep = capi.tile_preprocess(s.levels[0], xy, P, "u8", width=W)
+    planes = capi.LevelPlanes(s.levels[0], P, width=W)
+    sums, keep = planes.stats(xy)
+    assert torch.equal(sums, ref_sums) and torch.equal(keep, ref_keep)
+    got = planes.gather(xy)
+    same = (got == ref_u8).flatten(1).all(1)
+    assert bool(same.all()), f"{int((~same).sum())} of {len(same)} windows differ, first {int((~same).nonzero()[0])}"
+    assert 0 < int(keep.sum()) < len(keep)
+
+
+def test_iter_level_planes_and_windows_paths_agree(slide):
+    for level in (0, 1, 2):
+        a = list(extract.iter_level(slide, level, out_format="u8", batch_windows=50, use_planes=True))
+        b = list(extract.iter_level(slide, level, out_format="u8", batch_windows=50, use_planes=False))
+        for pa, pb in zip(a, b):
+            for k in ("x", "sums", "keep", "labels", "xy"):
+                assert torch.equal(pa[k], pb[k]), (level, k)
+
+
+def test_cell_labels_equal_window_scan(slide):
+    """Lattice labels from 224x224 mask cells == the direct per-window mask scan."""
+    for level in (0, 1, 2, 3):
+        lw = extract.LevelWindows(slide, level)
+        direct = capi.window_labels(slide.mask(level), lw.xy, lw.P)
+        assert torch.equal(lw.labels, direct), level
+        assert int(direct.sum()) > 0
