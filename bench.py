@@ -101,6 +101,27 @@ def cpu_baseline(n_sample: int = 256):
                       f"{dt:.1f} s of CPU work"}
 
 
+def cpu_baseline_wsi(side: int = 4000):
+    """Oracle extractor + Pillow resize + normalise (no PNG I/O, no network) on a bounded
+    crop of the same kind of synthetic slide, single process like the reference's loop."""
+    from oracle import extractor_ref, transform_ref
+
+    levels = synth.build_pyramid(synth.synth_level0(side, side, seed=10, n_blobs=6), 4)
+    slide = extractor_ref.ArraySlide([l.numpy() for l in levels])
+    t0 = time.time()
+    n_win = n_kept = 0
+    for level in (0, 1, 2, 3):
+        wins, pix = extractor_ref.extract_patches_ref(slide, level)
+        n_win += len(wins)
+        for p in pix:
+            transform_ref.eval_transform(p)
+            n_kept += 1
+    dt = time.time() - t0
+    return {"value": n_win / dt, "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"{side}x{side} level-0 crop, levels 0-3, reference stride 224: {n_win} windows, {n_kept} kept, "
+                      f"extractor + Pillow resize + normalise only (no ResNet), {dt:.1f} s of CPU work"}
+
+
 def run_resnet(args, rank, world, dev):
     B = args.batch
     sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
@@ -129,7 +150,7 @@ def run_resnet(args, rank, world, dev):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert out[1].shape[0] == B * world
@@ -199,11 +220,31 @@ def run_wsi(args, rank, world, dev):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     unique_bytes = sum(w * h * 3 for (w, h) in slide.level_dimensions)
-    return {
+    extra = {}
+    if rank == 0:
+        # dominant HBM-bound kernel of this workload: the level-0 resampler (hpass + vpass).
+        # algorithmic bytes = every level-0 source byte once (unique bytes)
+        w0, h0 = slide.level_dimensions[0]
+        capi.LevelPlanes(slide.levels[0], 1792, width=w0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            capi.LevelPlanes(slide.levels[0], 1792, width=w0)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        gbs = w0 * h0 * 3 / (ms * 1e-3) / 1e9
+        extra["roofline"] = {"bound": "hbm", "kernel": "hipac_level_build_planes[level 0: hpass_kernel<8> + vpass_kernel<8>]",
+                             "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                             "traffic": None, "launch_ms": ms, "bytes_per_launch": w0 * h0 * 3}
+        if world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline_wsi()
+    return {**extra,
         "metric": "whole-WSI wall-clock (levels 0-3)", "value": dt / args.steps, "unit": "s/slide", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8+" + args.precision, "data": "synthetic",
@@ -226,14 +267,19 @@ def main():
     ap.add_argument("--grid", choices=["reference", "nonoverlap"], default="reference")
     ap.add_argument("--batch_windows", type=int, default=4096)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--one_device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
-    rank, world, local = hdist.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if args.one_device:
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    rank, world, local = hdist.init_from_env(args.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if args.one_device else local)
     torch.cuda.set_device(dev)
     rec = run_resnet(args, rank, world, dev) if args.workload == "resnet" else run_wsi(args, rank, world, dev)
     if rank == 0:

@@ -61,6 +61,8 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     rank order."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # gloo has no CUDA all_gather: stage through the host
+        return all_gather_rows(t.cpu(), group).to(t.device)
     world = dist.get_world_size(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
