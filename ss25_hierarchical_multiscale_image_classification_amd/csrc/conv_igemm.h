@@ -925,6 +925,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#ifdef HIPAC_ABL_STEM_NO_MFMA
+    if (n_tiles < 0)
+#endif
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
@@ -939,6 +942,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       }
     }
     // bias + ReLU -> LDS stem tile [pixel][64 ch]; out-of-image stem pixels become 0
+#ifdef HIPAC_ABL_STEM_NO_EPI
+    if (n_tiles < 0)
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool inside = (sy0 + ly[i]) >= 0 && (sx0 + lx[i]) >= 0 && P[i] < NPX;
@@ -957,6 +963,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]
     if (more) stash(buf ^ 1);  // patch[buf^1] (raw window) was last read in the previous iteration
     // 3x3/2 max-pool of the tile: pooled pixel x 8 channels per thread item
+#ifdef HIPAC_ABL_STEM_NO_POOL
+    if (n_tiles < 0)
+#endif
     for (int item = tid; item < PTH * PTW * 8; item += 256) {
       const int pp = item >> 3, c8 = item & 7;
       const int py = pp / PTW, px = pp - py * PTW;
@@ -974,7 +983,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     }
     __syncthreads();  // pooling reads done (stem tile free) and patch[buf ^ 1] / raw window visible
     if constexpr (U8IN) {
+#ifndef HIPAC_ABL_STEM_NO_CONVERT
       if (more) convert(tile + gridDim.x, buf ^ 1);
+#endif
       __syncthreads();
     }
   }

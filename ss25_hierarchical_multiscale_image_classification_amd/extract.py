@@ -184,13 +184,11 @@ def iter_level(slide: DeviceSlide, level: int, out_format: str = "bf16", batch_w
         yield {"x": out, "xy": xy, "sums": sums, "keep": keep, "labels": labels}
 
 
-def scan_level(slide: DeviceSlide, level: int, **kw) -> LevelScan:
+def scan_level(slide: DeviceSlide, level: int, stride: Optional[int] = None, pad: bool = True, **_ignored) -> LevelScan:
     """Decisions only (no pixels kept): the device-side equivalent of one
     ``extract_patches(level=...)`` pass over one slide."""
-    parts = list(iter_level(slide, level, out_format=kw.pop("out_format", "u8"), kept_only=True, **kw))
-    P = PATCH_SIZES.get(level, 224)
-    cat = lambda k: torch.cat([p[k] for p in parts]) if parts else torch.empty(0)
-    return LevelScan(level, P, cat("xy"), cat("sums"), cat("keep"), cat("labels"))
+    lw = LevelWindows(slide, level, stride=stride, pad=pad)
+    return LevelScan(level, lw.P, lw.xy, lw.sums, lw.keep, lw.labels)
 
 
 class LevelWindows:

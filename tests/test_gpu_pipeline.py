@@ -59,3 +59,30 @@ def test_png_tree_flow_equals_fused_flow(tmp_path):
     order = [by_name[p.replace("\\", "/").split("/")[-1]] for p in paths_png]
     assert torch.equal(f_png, f_fused[order])
     assert np.array_equal(lab_png, lab_fused[order])
+
+
+def test_cli_patch_then_extract_features(tmp_path, monkeypatch):
+    """The reference's flag surface end to end on a synthetic slide: --patch writes the
+    level tree (manifest + PNGs named like src/main.py:722), --extract_features writes the
+    three files of src/main.py:885-893."""
+    from ss25_hierarchical_multiscale_image_classification_amd.main import main
+
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / "data" / "camelyon16")
+    assert main(["--patch", "--patch_level", "1", "--synthetic", "1500,1300,33,normal_042", "--write_png",
+                 "--data_root", root]) == 0
+    level_dir = tmp_path / "data" / "camelyon16" / "patches" / "level_1" / "normal_042"
+    man = np.load(level_dir / "manifest.npz")
+    pngs = sorted(p.name for p in level_dir.glob("*.png"))
+    assert len(pngs) == int(man["keep"].sum()) > 1
+    assert all(n.startswith("normal_042_x") and (n.endswith("_normal.png") or n.endswith("_tumor.png")) for n in pngs)
+    # resume rule (src/main.py:634-640): a non-empty slide directory is skipped
+    assert main(["--patch", "--patch_level", "1", "--synthetic", "1500,1300,33,normal_042", "--data_root", root]) == 0
+    assert main(["--extract_features", "--patch_level", "1", "--data_root", root, "--precision", "fp16"]) == 0
+    feats = np.load(tmp_path / "patch_features_1.npy")
+    labels = np.load(tmp_path / "patch_labels_1.npy")
+    paths = (tmp_path / "patch_paths_1.txt").read_text().split()
+    assert sorted(int("_tumor" in p) for p in paths) == sorted(labels.tolist())
+    assert feats.shape == (len(pngs), 512) and feats.dtype == np.float32
+    assert labels.shape == (len(pngs),) and labels.dtype == np.int64 and len(paths) == len(pngs)
+    assert np.isfinite(feats).all() and float(np.abs(feats).max()) > 0
