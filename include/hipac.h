@@ -43,6 +43,7 @@ extern "C" {
 /* arithmetic type of the network's MFMA operands (accumulation is always fp32) */
 #define HIPAC_PREC_BF16 0
 #define HIPAC_PREC_FP16 1
+#define HIPAC_PREC_FP32 2  /* parity mode: fp32 storage, exact f32 MFMA (1/16 of the bf16 rate); no uint8 input */
 
 /* input layouts accepted by hipac_resnet18_forward */
 #define HIPAC_IN_NCHW_F32 0   /* float32[B,3,224,224], the reference's layout (src/main.py:870) */

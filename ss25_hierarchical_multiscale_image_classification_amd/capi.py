@@ -19,13 +19,14 @@ import torch
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")  # override: A/B builds of the same ABI
 
-PREC_BF16, PREC_FP16 = 0, 1
+PREC_BF16, PREC_FP16, PREC_FP32 = 0, 1, 2
 IN_NCHW_F32, IN_NHWC4_PAD, IN_U8_HWC = 0, 1, 2
 OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
 PATCH, PAD_H, PAD_W = 224, 230, 232
 
-PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16}
-TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
+# "fp32" is the parity mode: fp32 storage and the exact f32 MFMA (about 1/16 of the bf16 rate)
+PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16, "fp32": PREC_FP32}
+TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16, PREC_FP32: torch.float32}
 
 
 class HipacError(RuntimeError):
@@ -272,6 +273,8 @@ class PackedResNet18:
             if tuple(x.shape[1:]) != (PATCH, PATCH, 3):
                 raise HipacError(f"uint8 input must be [B,224,224,3], got {tuple(x.shape)}")
             layout = IN_U8_HWC
+            if self.precision == "fp32":  # parity mode has no fused uint8 stem: normalise first (bit-exact LUT)
+                x, layout, native_layout = patches_normalize(x, "nchw_f32"), IN_NCHW_F32, False
         elif native_layout:
             if tuple(x.shape[1:]) != (PAD_H, PAD_W, 4) or x.dtype != TORCH_DTYPE[PRECISIONS[self.precision]]:
                 raise HipacError(f"native input must be {self.precision}[B,{PAD_H},{PAD_W},4], got {x.dtype}{tuple(x.shape)}")

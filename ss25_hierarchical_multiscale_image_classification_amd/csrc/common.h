@@ -45,6 +45,20 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// fp32 parity mode: exact f32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate).  A fragment is
+// the same "8 consecutive k of one row" as for bf16; MFMA t of a k16 step consumes element t of both
+// operands, i.e. the k pair {t, 8 + t} (lane halves), so the 8 instructions cover all 16 k.
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <> struct Elem<float> {
+  using frag = f32x8;
+  using vec4 = f32x4;
+  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], c, 0, 0, 0);
+    return c;
+  }
+};
+
 // Fixed ResNet18@224 geometry.
 constexpr int kPatch = HIPAC_PATCH;
 constexpr int kPadH = HIPAC_PAD_H;
@@ -94,6 +108,7 @@ struct Net {
 // Offsets are bytes into the caller's workspace; T = 2-byte element.
 struct Plan {
   int bc, gc;
+  int esz;        // bytes per activation element: 2 (bf16 / fp16) or 4 (fp32 parity mode)
   int u8_input;   // 1: the stem reads raw uint8 HWC patches (normalise fused); needs fuse_stem
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   // early, sized for bc images
@@ -109,7 +124,7 @@ struct Plan {
   size_t blk[8];
   size_t total;
 };
-Plan make_plan(int batch);
+Plan make_plan(int batch, int precision = 0);
 constexpr int kNumOps = 21;
 constexpr int kNumEarlyOps = 11;  // stem, pool, layer1 (4), layer2 (5)
 
@@ -119,6 +134,8 @@ constexpr int kNumEarlyOps = 11;  // stem, pool, layer1 (4), layer2 (5)
 int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                    hipStream_t s, int first, int last);
 int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                  hipStream_t s, int first, int last);
+int run_trunk_f32(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                   hipStream_t s, int first, int last);
 
 // elementwise.hip

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
   constexpr int BK = STEM ? 32 : 64;
   constexpr int KT = STEM ? 7 : KS * KS * (CIN / 64);
   constexpr int KTOT = KT * BK;
-  constexpr int LDA = BK + 8;  // padded LDS row, elements
-  constexpr int CH = BK / 8;   // 16-byte chunks per row
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk: 8 (bf16/fp16) or 4 (fp32)
+  constexpr int LDA = BK + EPC;             // LDS row padded by one chunk, elements
+  constexpr int CH = BK / EPC;              // 16-byte chunks per row
   constexpr int BM = 128;
   constexpr int RPP = 256 / CH;       // rows covered per pass of the 256 threads
   constexpr int APT = BM / RPP;       // A pieces per thread
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
     if constexpr (STEM) {
       a_ih0[i] = 0;
       a_iw0[i] = 0;
-      a_base[i] = ((b * kPadH + 2 * oh) * kPadW + 2 * ow) * 4 + chunk * 8;
+      a_base[i] = ((b * kPadH + 2 * oh) * kPadW + 2 * ow) * 4 + chunk * EPC;
     } else {
       a_ih0[i] = oh * STRIDE - PAD;
       a_iw0[i] = ow * STRIDE - PAD;
-      a_base[i] = ((b * HI + a_ih0[i]) * WI + a_iw0[i]) * CIN + chunk * 8;
+      a_base[i] = ((b * HI + a_ih0[i]) * WI + a_iw0[i]) * CIN + chunk * EPC;
     }
   }
-  const T* wsrc = wgt + (size_t)(n0 + row0) * KTOT + chunk * 8;
+  const T* wsrc = wgt + (size_t)(n0 + row0) * KTOT + chunk * EPC;
 
   u32x4 areg[APT], wreg[WPT];  // native vectors: HIP's uint4 struct copies lower to memcpy and land in scratch
   // Branch-free staging: out-of-image taps load from offset 0 and are zeroed by
@@ -127,11 +128,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
   for (int t = 0; t < KT; ++t) {
     static_for<APT>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      *reinterpret_cast<u32x4*>(As + (row0 + i * RPP) * LDA + chunk * 8) = areg[i];
+      *reinterpret_cast<u32x4*>(As + (row0 + i * RPP) * LDA + chunk * EPC) = areg[i];
     });
     static_for<WPT>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      *reinterpret_cast<u32x4*>(Ws + (row0 + i * RPP) * LDA + chunk * 8) = wreg[i];
+      *reinterpret_cast<u32x4*>(Ws + (row0 + i * RPP) * LDA + chunk * EPC) = wreg[i];
     });
     __syncthreads();
     // advance (kh, kw, cc) to tile t+1 and prefetch it behind the MFMAs
@@ -1225,7 +1226,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
   constexpr int HO = STEM ? 112 : (HI + 2 * PAD - KS) / STRIDE + 1;
   constexpr int WO = STEM ? 112 : (WI + 2 * PAD - KS) / STRIDE + 1;
   const int M = n * HO * WO;
-  if constexpr (STEM) {
+  if constexpr (STEM || sizeof(T) == 4) {
+    // the stem, and every layer of the fp32 parity mode (exact f32 MFMA), run on the v1 kernel
     constexpr int BN = 64;
     dim3 grid((M + 127) / 128, COUT / BN);
     hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
@@ -1327,7 +1329,9 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
                      hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
   const int ne = n_early, nl = n_late;
-  if (p.fuse_stem) {
+  bool fused_done = false;
+  if constexpr (sizeof(T) == 2) {
+    if (p.fuse_stem) {
     // op 0 = fused stem + max-pool (the 112x112 stem map is never materialised), op 1 = nothing
     if (ops.take()) {
       const int n_tiles = ne * 56;
@@ -1342,7 +1346,10 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       HIPAC_TRY((int)hipGetLastError());
     }
     (void)ops.take();
-  } else {
+      fused_done = true;
+    }
+  }
+  if (!fused_done) {
   if (ops.take())
     HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
   if (ops.take()) {
@@ -1351,7 +1358,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
                        (const T*)(ws + p.stem), (T*)(ws + p.pool), ne);
     HIPAC_TRY((int)hipGetLastError());
   }
-  }
+    }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
   char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * sizeof(T);
   HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops)));

@@ -38,6 +38,7 @@ static inline uint16_t f32_to_f16_bits(float f) {
 static inline uint16_t to_bits(float f, int precision) {
   return precision == HIPAC_PREC_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
 }
+static inline int elem_size(int precision) { return precision == HIPAC_PREC_FP32 ? 4 : 2; }
 
 static int env_int(const char* name, int dflt, int lo, int hi) {
   if (const char* e = getenv(name)) {
@@ -47,15 +48,16 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
   return dflt;
 }
 
-Plan make_plan(int batch) {
+Plan make_plan(int batch, int precision) {
   Plan p;
+  p.esz = elem_size(precision);
   // bc: early sub-batch -- 512 images give layer1/2 thousands of tiles (block-round
   // quantisation < 10 %).  gc: late group -- layer4 has only 49 pixels per image, so it
   // needs thousands of images (default group 4096) to fill 256 CUs x 2 workgroups for several rounds.
   // (tuning knobs; a whole run must use one setting)
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
   const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
-  p.fuse_stem = env_int("HIPAC_FUSE_STEM", 1, 0, 1);
+  p.fuse_stem = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
@@ -69,20 +71,21 @@ Plan make_plan(int batch) {
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  p.xin = take(b * kPadH * kPadW * 4 * 2);
-  p.stem = take(b * 112 * 112 * 64 * 2);
-  p.pool = take(b * 56 * 56 * 64 * 2);
-  p.tmp_e = take(b * 56 * 56 * 64 * 2);
-  p.ds_e = take(b * 28 * 28 * 128 * 2);
-  p.blk[0] = take(b * 56 * 56 * 64 * 2);
-  p.blk[1] = take(b * 56 * 56 * 64 * 2);
-  p.blk[2] = take(b * 28 * 28 * 128 * 2);
-  p.blk[3] = take(g * 28 * 28 * 128 * 2);
-  p.tmp_l = take(g * 14 * 14 * 256 * 2);
-  p.ds_l = take(g * 14 * 14 * 256 * 2);
-  p.blk[4] = take(g * 14 * 14 * 256 * 2);
-  p.blk[5] = take(g * 14 * 14 * 256 * 2);
-  p.blk[6] = take(g * 7 * 7 * 512 * 2);
+  const size_t e = (size_t)p.esz;
+  p.xin = take(b * kPadH * kPadW * 4 * e);
+  p.stem = take(b * 112 * 112 * 64 * e);
+  p.pool = take(b * 56 * 56 * 64 * e);
+  p.tmp_e = take(b * 56 * 56 * 64 * e);
+  p.ds_e = take(b * 28 * 28 * 128 * e);
+  p.blk[0] = take(b * 56 * 56 * 64 * e);
+  p.blk[1] = take(b * 56 * 56 * 64 * e);
+  p.blk[2] = take(b * 28 * 28 * 128 * e);
+  p.blk[3] = take(g * 28 * 28 * 128 * e);
+  p.tmp_l = take(g * 14 * 14 * 256 * e);
+  p.ds_l = take(g * 14 * 14 * 256 * e);
+  p.blk[4] = take(g * 14 * 14 * 256 * e);
+  p.blk[5] = take(g * 14 * 14 * 256 * e);
+  p.blk[6] = take(g * 7 * 7 * 512 * e);
   p.blk[7] = take(g * 7 * 7 * 512 * 4);
   p.total = off;
   return p;
@@ -119,8 +122,10 @@ int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStr
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (precision == HIPAC_PREC_BF16)
     hipLaunchKernelGGL((nchw_to_nhwc4_kernel<__bf16>), dim3(grid), dim3(256), 0, s, x, (__bf16*)out, n);
-  else
+  else if (precision == HIPAC_PREC_FP16)
     hipLaunchKernelGGL((nchw_to_nhwc4_kernel<_Float16>), dim3(grid), dim3(256), 0, s, x, (_Float16*)out, n);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(grid), dim3(256), 0, s, x, (float*)out, n);
   return (int)hipGetLastError();
 }
 
@@ -199,7 +204,7 @@ int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, 
                       hipStream_t s) {
   const long long total = (long long)n * C * H * W;
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (is_f32)
+  if (is_f32 || precision == HIPAC_PREC_FP32)
     hipLaunchKernelGGL((tap_export_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, dst, n, C, H, W);
   else if (precision == HIPAC_PREC_BF16)
     hipLaunchKernelGGL((tap_export_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, dst, n, C, H,
@@ -224,7 +229,9 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
   HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
                 "pack: null tensor pointer (cout=%d cin=%d ks=%d)", cout, cin, ks);
   const int K = stem ? 7 * 32 : ks * ks * cin;
-  std::vector<uint16_t> w((size_t)cout * K, 0);
+  const bool f32 = precision == HIPAC_PREC_FP32;
+  std::vector<uint16_t> w(f32 ? 0 : (size_t)cout * K, 0);
+  std::vector<float> w32(f32 ? (size_t)cout * K : 0, 0.f);
   std::vector<float> bias(cout);
   for (int o = 0; o < cout; ++o) {
     const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
@@ -234,10 +241,11 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
         for (int kw = 0; kw < ks; ++kw) {
           const float v = (float)((double)c.conv_w[(((size_t)o * cin + i) * ks + kh) * ks + kw] * scale);
           const size_t k = stem ? (size_t)kh * 32 + kw * 4 + i : ((size_t)kh * ks + kw) * cin + i;
-          w[(size_t)o * K + k] = to_bits(v, precision);
+          if (f32) w32[(size_t)o * K + k] = v;
+          else w[(size_t)o * K + k] = to_bits(v, precision);
         }
   }
-  int rc = upload(w.data(), w.size() * 2, &out->w);
+  int rc = f32 ? upload(w32.data(), w32.size() * 4, &out->w) : upload(w.data(), w.size() * 2, &out->w);
   if (rc) return rc;
   return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
 }
@@ -277,8 +285,8 @@ void hipac_weights_free(hipac_weights_t* w) {
 
 int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hipac_weights_t** out) {
   HIPAC_REQUIRE(params && out, HIPAC_EINVAL, "pack: null argument");
-  HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16, HIPAC_EINVAL,
-                "pack: unknown precision %d", precision);
+  HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16 || precision == HIPAC_PREC_FP32,
+                HIPAC_EINVAL, "pack: unknown precision %d", precision);
   HIPAC_REQUIRE(params->num_classes >= 0 && params->num_classes <= 16, HIPAC_EINVAL,
                 "pack: num_classes %d out of range", params->num_classes);
   HIPAC_REQUIRE((params->num_classes == 0) == (params->fc_w == nullptr), HIPAC_EINVAL,
@@ -311,7 +319,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
       for (int v = 0; v < 256; ++v) {
         const float t = (float)v / 255.0f;
         const float d = t - mean[c];
-        lut[c * 256 + v] = to_bits(d / stdv[c], precision);
+        lut[c * 256 + v] = to_bits(d / stdv[c], precision == HIPAC_PREC_FP32 ? HIPAC_PREC_BF16 : precision);
       }
     rc = upload(lut.data(), lut.size() * 2, (void**)&w->net.lut_t);
   }
@@ -332,9 +340,8 @@ int hipac_weights_precision(const hipac_weights_t* w) { return w ? w->net.precis
 int hipac_weights_num_classes(const hipac_weights_t* w) { return w ? w->net.num_classes : HIPAC_EINVAL; }
 
 size_t hipac_resnet18_workspace_bytes(int batch, int precision) {
-  (void)precision;
   if (batch <= 0) return 0;
-  return make_plan(batch).total;
+  return make_plan(batch, precision).total;
 }
 
 int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, int in_layout, float* feats,
@@ -347,17 +354,18 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
                 "forward: logits/labels requested but the weights carry no fc (fc = Identity)");
   HIPAC_REQUIRE(((uintptr_t)workspace & 255) == 0, HIPAC_EINVAL, "forward: workspace must be 256-byte aligned");
   HIPAC_REQUIRE(((uintptr_t)x & 15) == 0, HIPAC_EINVAL, "forward: x must be 16-byte aligned");
-  Plan p = make_plan(batch);
+  Plan p = make_plan(batch, w->net.precision);
   HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
                 workspace_bytes, p.total);
   HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem, HIPAC_EUNSUPPORTED,
-                "forward: uint8 input needs the fused stem (unset HIPAC_FUSE_STEM=0)");
+                "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0)");
   p.u8_input = in_layout == HIPAC_IN_U8_HWC;
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const Net& net = w->net;
-  const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * 2;
-  auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+  const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * p.esz;
+  auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
+               : net.precision == HIPAC_PREC_FP16 ? run_trunk_f16 : run_trunk_f32;
   for (int g0 = 0; g0 < batch; g0 += p.gc) {
     const int gn = batch - g0 < p.gc ? batch - g0 : p.gc;
     for (int b0 = 0; b0 < gn; b0 += p.bc) {
@@ -388,7 +396,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
 int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layout, void* workspace,
                            size_t workspace_bytes, int batch, int first_op, int last_op, void* stream) {
   HIPAC_REQUIRE(w && workspace, HIPAC_EINVAL, "run_ops: null argument");
-  Plan p = make_plan(batch);
+  Plan p = make_plan(batch, w->net.precision);
   HIPAC_REQUIRE(batch > 0 && batch <= p.gc, HIPAC_EINVAL, "run_ops: batch %d exceeds one group (%d)", batch, p.gc);
   HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "run_ops: workspace %zu < required %zu",
                 workspace_bytes, p.total);
@@ -399,7 +407,8 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
   HIPAC_REQUIRE(first_op > 0 || x != nullptr || in_layout == HIPAC_IN_NCHW_F32, HIPAC_EINVAL,
                 "run_ops: op 0 needs the input batch");
   char* ws = (char*)workspace;
-  auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+  auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
+               : w->net.precision == HIPAC_PREC_FP16 ? run_trunk_f16 : run_trunk_f32;
   // early ops act on the first sub-batch, late ops on the whole group; an NCHW input was
   // converted into the workspace by the preceding forward
   p.u8_input = in_layout == HIPAC_IN_U8_HWC && p.fuse_stem;
@@ -411,7 +420,7 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
 int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap, float* dst,
                        void* stream) {
   HIPAC_REQUIRE(w && workspace && dst, HIPAC_EINVAL, "tap: null argument");
-  const Plan p = make_plan(batch);
+  const Plan p = make_plan(batch, w->net.precision);
   HIPAC_REQUIRE(batch > 0 && batch <= p.bc, HIPAC_EINVAL, "tap: batch %d exceeds one sub-batch (%d)", batch, p.bc);
   HIPAC_REQUIRE(tap >= 0 && tap <= 9, HIPAC_EINVAL, "tap: index %d", tap);
   const char* ws = (const char*)workspace;

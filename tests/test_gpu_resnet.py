@@ -4,10 +4,13 @@ committed golden vectors.
 Tolerances (norm-relative: max|a-b| / max|b| per tensor), with the values measured on
 MI355X in round 1 in brackets -- the arithmetic is fp32-accumulated MFMA on operands
 rounded to the named type, so the error is rounding only and grows ~sqrt(depth):
+    fp32 : features 2e-5   logits 2e-5   taps 2e-5   (parity mode: fp32 storage, exact f32 MFMA; the
+           only differences from the oracle are BN folding and summation order)
     fp16 : features 2.5e-3 [5e-4]   logits 2.5e-3 [9e-4]   intermediate taps 3e-3 [<=1.3e-3]
     bf16 : features 2.5e-2 [4e-3]   logits 2.5e-2 [7e-3]   intermediate taps 3e-2 [<=1.0e-2]
-north_star's 1e-3 (fp32-relative) is met by the fp16 mode on the logits; bf16 (the
-BASELINE dtype) cannot meet it by construction (8-bit mantissa) -- see DESIGN.md.
+north_star's 1e-3 (fp32-relative) is met with two orders of magnitude to spare by the fp32
+mode and, on features, by the fp16 mode; bf16 (the BASELINE dtype, the one benchmarked) cannot
+meet it by construction (8-bit mantissa, 20 roundings deep) -- see DESIGN.md.
 Labels must be identical wherever the oracle's margin |l0-l1| exceeds twice the
 logit error bound; near-ties are counted and reported, not hidden.
 """
@@ -19,7 +22,7 @@ from oracle import resnet18_ref as R, transform_ref as T
 from ss25_hierarchical_multiscale_image_classification_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp16": dict(out=2.5e-3, tap=3e-3), "bf16": dict(out=2.5e-2, tap=3e-2)}
+TOL = {"fp16": dict(out=2.5e-3, tap=3e-3), "bf16": dict(out=2.5e-2, tap=3e-2), "fp32": dict(out=2e-5, tap=2e-5)}
 TAPS = ["stem", "maxpool"] + [f"layer{s}.{k}" for s in (1, 2, 3, 4) for k in (0, 1)]
 
 
@@ -40,7 +43,7 @@ def golden_sd(golden, seed):
     return sd
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 @pytest.mark.parametrize("seed", [0, 1])
 def test_golden_features_logits_labels(golden, prec, seed):
     u8 = torch.from_numpy(golden["patches_u8"]).cuda()
@@ -57,7 +60,7 @@ def test_golden_features_logits_labels(golden, prec, seed):
     assert np.array_equal(lab.cpu().numpy()[decided], golden[f"s{seed}_labels"][decided])
     assert torch.equal(lab, l.argmax(1))  # in-kernel argmax == torch.argmax of our own logits
     for i, name in enumerate(TAPS):
-        if i == 0:
+        if i == 0 and prec != "fp32":
             continue  # the stem map is not materialised (fused with the max-pool); see test_unfused_stem_path
         t = net.tap(u8.shape[0], i)[0, :4, :2]
         ref = torch.from_numpy(golden[f"s{seed}_tap_{name}"])
@@ -65,7 +68,7 @@ def test_golden_features_logits_labels(golden, prec, seed):
         assert float((t.cpu() - ref).abs().max()) <= TOL[prec]["tap"] * scale, name
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 def test_full_taps_against_oracle_random_patches(prec):
     sd = synth.seeded_resnet18_state_dict(2, num_classes=2)
     u8 = synth.synth_patches_u8(5, seed=11)
@@ -76,7 +79,7 @@ def test_full_taps_against_oracle_random_patches(prec):
     f, l, _ = net.forward(x.cuda(), want_feats=True, want_logits=True)
     assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
     for i, name in enumerate(TAPS):
-        if i == 0:
+        if i == 0 and prec != "fp32":
             with pytest.raises(capi.HipacError):
                 net.tap(5, 0)
             continue
@@ -202,3 +205,19 @@ def test_reference_class_surface_on_gpu():
         assert rel(uni.cuda().eval()(x.cuda()), ref_f) <= TOL["fp16"]["out"]
     with pytest.raises(capi.HipacError):
         uni(x)  # eval-mode CPU tensor: no CPU fallback
+
+
+def test_fp32_parity_mode_meets_1e3_with_margin_and_labels_exactly():
+    """The strict form of north_star's gate: logits / features within 1e-3 of the fp32 oracle
+    (here: < 2e-5) and per-patch labels identical, on 24 seeded patches incl. uint8 input."""
+    sd = synth.seeded_resnet18_state_dict(7, num_classes=2)
+    u8 = synth.synth_patches_u8(24, seed=31)
+    x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+    ref_f, ref_l = R.resnet18_forward(x, sd)
+    net = capi.PackedResNet18(sd, precision="fp32")
+    f, l, lab = net.forward(u8.cuda(), want_logits=True, want_labels=True)  # uint8 in: normalised by the LUT kernel
+    assert rel(f, ref_f) < 2e-5 and rel(l, ref_l) < 2e-5
+    elem = float(((f.cpu() - ref_f).abs() / ref_f.abs().clamp_min(1e-3)).max())
+    assert elem < 1e-3  # element-wise relative, not just norm-relative
+    margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
+    assert torch.equal(lab.cpu()[margin > 1e-5], ref_l.argmax(1)[margin > 1e-5])

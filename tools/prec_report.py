@@ -1,0 +1,23 @@
+"""Developer tool (GPU box): measured error of each precision mode against the fp32 oracle on the
+golden patches + 24 random patches, and the throughput of the fp32 parity mode."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import resnet18_ref as R, transform_ref as T
+from ss25_hierarchical_multiscale_image_classification_amd import capi, synth
+sd = synth.seeded_resnet18_state_dict(7, num_classes=2)
+u8 = synth.synth_patches_u8(24, seed=31)
+x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+ref_f, ref_l = R.resnet18_forward(x, sd)
+rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+for prec in ("fp32", "fp16", "bf16"):
+    net = capi.PackedResNet18(sd, precision=prec)
+    f, l, lab = net.forward(u8.cuda(), want_logits=True, want_labels=True)
+    elem = float(((f.cpu() - ref_f).abs() / ref_f.abs().clamp_min(1e-3)).max())
+    print(f"{prec}: features norm-rel {rel(f, ref_f):.2e} elementwise-rel {elem:.2e}  logits norm-rel {rel(l, ref_l):.2e} "
+          f"abs {float((l.cpu()-ref_l).abs().max()):.2e}  labels equal {int((lab.cpu()==ref_l.argmax(1)).sum())}/24")
+net = capi.PackedResNet18(sd, precision="fp32")
+xb = torch.randn(2048, 3, 224, 224, device="cuda")
+net.forward(xb); torch.cuda.synchronize()
+t0 = time.time(); net.forward(xb); torch.cuda.synchronize(); dt = time.time() - t0
+print(f"fp32 parity mode: {2048/dt:.0f} patches/s ({2048/dt*3.627e9/1e12:.1f} TFLOP/s, f32 MFMA peak 157)")
