@@ -145,16 +145,36 @@ __global__ __launch_bounds__(256) void hpass_kernel(const uint8_t* __restrict__ 
     unsigned d[NDW];
     const bool row_ok = y < H;
     const uint8_t* rowp = level + (long long)y * pitch;
+    // fast path (almost every thread): the whole cover lies inside the row's real pixels ->
+    // 16-byte (and one 8-byte) loads, no masking.  The base is only 4-byte aligned, which is
+    // all global_load_dwordx4 needs.
+    if (live && row_ok && cb >= 0 && cb + 4 * NDW <= wbytes) {
+      const uint8_t* q = rowp + cb;
 #pragma unroll
-    for (int k = 0; k < NDW; ++k) {
-      const long long o = cb + 4 * k;
-      unsigned v = 0xffffffffu;
-      if (live && row_ok && o >= 0 && o + 4 <= pitch) {
-        v = *reinterpret_cast<const unsigned*>(rowp + o);
-        const long long nv = wbytes - o;  // valid bytes in this dword
-        if (nv < 4) v |= nv <= 0 ? 0xffffffffu : (0xffffffffu << (8 * (int)nv));
+      for (int k = 0; k + 4 <= NDW; k += 4) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(q + 4 * k);
+        d[k] = v[0];
+        d[k + 1] = v[1];
+        d[k + 2] = v[2];
+        d[k + 3] = v[3];
       }
-      d[k] = v;
+      if constexpr (NDW % 4 == 2) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(q + 4 * (NDW - 2));
+        d[NDW - 2] = v[0];
+        d[NDW - 1] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDW; ++k) {
+        const long long o = cb + 4 * k;
+        unsigned v = 0xffffffffu;
+        if (live && row_ok && o >= 0 && o + 4 <= pitch) {
+          v = *reinterpret_cast<const unsigned*>(rowp + o);
+          const long long nv = wbytes - o;  // valid bytes in this dword
+          if (nv < 4) v |= nv <= 0 ? 0xffffffffu : (0xffffffffu << (8 * (int)nv));
+        }
+        d[k] = v;
+      }
     }
     if (live) {
       // whiteness: bytes [24h, 24h+24) = cover dwords CB0/4 .. CB0/4+5
