@@ -65,8 +65,13 @@ def downsample2x(img: torch.Tensor) -> torch.Tensor:
     """uint8[H,W,3] -> uint8[H//2,W//2,3]: 2x2 box mean, round half up.
     (Ours: the reference reads pre-built TIFF levels and never downsamples.)"""
     h2, w2 = img.shape[0] // 2, img.shape[1] // 2
-    a = img[: h2 * 2, : w2 * 2].view(h2, 2, w2, 2, 3).to(torch.int32)
-    return ((a.sum(dim=(1, 3)) + 2) >> 2).to(torch.uint8)
+    out = torch.empty((h2, w2, 3), dtype=torch.uint8, device=img.device)
+    band = 4096  # output rows per pass: bounds the int32 temporaries for 100k-wide slides
+    for r0 in range(0, h2, band):
+        r1 = min(h2, r0 + band)
+        a = img[2 * r0: 2 * r1, : w2 * 2].reshape(r1 - r0, 2, w2, 2, 3).to(torch.int32)
+        out[r0:r1] = ((a.sum(dim=(1, 3)) + 2) >> 2).to(torch.uint8)
+    return out
 
 
 def build_pyramid(level0: torch.Tensor, n_levels: int = 4) -> List[torch.Tensor]:
