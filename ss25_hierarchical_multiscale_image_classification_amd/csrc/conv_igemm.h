@@ -453,30 +453,18 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
 // pixel offsets.  Only the weight tile (BN x 64 channels per tap) still streams, through a
 // 2-slot LDS-DMA ring one tap ahead of the MFMAs.
 //
-// Geometry: output pixels are flattened m = (b*H + y)*W + x; in zero-padded coordinates
-// (rows 0..H+1 per image, cols 0..W+1) tap (kh,kw) of pixel (b,y,x) reads padded row
-// b*(H+2) + y + kh, col x + kw.  The band a workgroup needs is the contiguous range of
-// padded rows [Rp(first pixel), Rp(last pixel) + 2] (it may cross image boundaries: the
-// bottom/top pad rows of neighbouring images are just zero rows in the band).  In LDS the
-// band is [pixel q = row*(W+2) + col][64 ch] with the same chunk swizzle as v2
-// (c ^ ((q >> 1) & 7)); a lane's read address for a tap is q0 + kh*(W+2) + kw.
+// Geometry: NHWC activations flattened over (image, row, col) are one pixel array m; tap
+// (kh,kw) of output pixel m reads pixel m + (kh-1)*W + (kw-1) unless that falls outside the
+// image (x or y edge), where it reads zeros.  So the band a workgroup needs is simply the
+// CONTIGUOUS pixel range [m0 - W - 1, mlast + W + 1] (it may run into neighbouring images;
+// those pixels are never selected because the edge flags redirect such taps).  In LDS:
+// slot 0 = a pixel of zeros, slot q >= 1 = pixel m0 - W - 2 + q, [slot][64 ch] with the chunk
+// swizzle of v2 (c ^ ((q >> 1) & 7)).  Consecutive output pixels sit in consecutive slots, so
+// every tap is conflict-free; edge taps read slot 0 (same address in all such lanes: an LDS
+// broadcast).  No per-piece div/mod, no pad rows: BM + 2W + 2 pixels per band.
 // ---------------------------------------------------------------------------------------
-template <int H, int W, int BM>
-constexpr int halo_rows_max() {
-  int best = 0;
-  for (int k = 0; k < 2 * H * W; ++k) {
-    const long long m0 = (long long)k * BM, m1 = m0 + BM - 1;
-    const int r0 = (int)((m0 / (H * W)) * (H + 2) + (m0 % (H * W)) / W);
-    const int r1 = (int)((m1 / (H * W)) * (H + 2) + (m1 % (H * W)) / W) + 2;
-    if (r1 - r0 + 1 > best) best = r1 - r0 + 1;
-  }
-  return best;
-}
+constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 1 + 7) / 8; }  // 8-pixel (1 KB) pieces
 
-// Band layout (v3b): the band is stored WITHOUT halo columns: slot 1 + row*W + x (slot 0 is
-// a pixel of zeros).  Consecutive output pixels then sit in consecutive slots even across
-// row wraps, so the swizzle stays conflict-free for every tap; a tap that falls left/right
-// of the image row reads slot 0 instead (same address in all such lanes: an LDS broadcast).
 // NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
 // Epilogue: the 128 x BN fp32 tile goes through LDS in two halves of 64 pixels so that
 // global traffic is 16-byte pieces of whole pixel rows (residual loads and stores).
@@ -490,12 +478,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   using frag = typename E::frag;
   constexpr int CC = CIN / 64;
   constexpr int KTOT = 9 * CIN;
-  constexpr int HPAD = H + 2;
   constexpr int WM = 2, WN = 2;                     // 4 waves: 2 pixel halves x 2 channel halves
   constexpr int MTW = BM / (WM * 32);               // 32-pixel sub-tiles per wave (2 or 4)
   constexpr int WTN = BN / WN, NT = WTN / 32;       // channels per wave, 32-wide tiles per wave
-  constexpr int ROWS_MAX = halo_rows_max<H, W, BM>();
-  constexpr int A_PIECES = (ROWS_MAX * W + 2 + 7) / 8;
+  constexpr int A_PIECES = halo_band_pieces(W, BM);
   constexpr int A_BYTES = A_PIECES * 1024;
   constexpr int W_BYTES = BN * 128;
   constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
@@ -525,13 +511,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   if (mt >= n_mtiles) return;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  // band of padded rows needed by pixels m0 .. min(m0+BM, M)-1
+  // band = the contiguous pixel range [m0 - W - 1, mlast + W + 1] of the flattened activation
   const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
-  const int b_first = m0 / (H * W), b_last = mlast / (H * W);
-  const int rp_lo = b_first * HPAD + (m0 - b_first * (H * W)) / W;
-  const int rp_hi = b_last * HPAD + (mlast - b_last * (H * W)) / W + 2;
-  const int npx = (rp_hi - rp_lo + 1) * W;       // real band pixels; slots 1..npx
-  const int npieces = (npx + 2 + 7) >> 3;
+  const int mstart = m0 - W - 1;
+  const int npx = mlast - m0 + 1 + 2 * W + 2;    // band pixels; slots 1..npx
+  const int npieces = (npx + 1 + 7) >> 3;
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -542,14 +526,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   auto issue_band = [&](int cc) {
     for (int p = wave; p < npieces; p += 4) {
       const int q = p * 8 + prow;                // slot
-      const int idx = q - 1;
-      const int rr = idx / W, x = idx - rr * W;
-      const int rp = rp_lo + rr;
-      const int b = rp / HPAD, y = rp - b * HPAD - 1;
-      const bool ok = q >= 1 && idx < npx && (unsigned)y < (unsigned)H && b < n_img;
+      const int mm = mstart + q - 1;             // flattened pixel held by this slot
+      const bool ok = q >= 1 && q <= npx && mm >= 0 && mm < M;
       const int schunk = dchunk ^ ((q >> 1) & 7);
-      const char* src = ok ? in_b + ((((size_t)b * H + y) * W + x) * CIN + cc * 64 + schunk * 8) * 2
-                           : zero_page + dchunk * 16;
+      const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
     }
   };
@@ -571,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 
   // ---- consumer side: slot of this lane's two output pixels for tap (0, centre column) ----
   int q0[MTW];
-  bool edgeL[MTW], edgeR[MTW];
+  bool edgeL[MTW], edgeR[MTW], edgeT[MTW], edgeB[MTW];
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
     int m = m0 + wm * (MTW * 32) + i * 32 + r;
@@ -579,9 +559,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     const int b = m / (H * W);
     const int rem = m - b * (H * W);
     const int y = rem / W, x = rem - y * W;
-    q0[i] = 1 + (b * HPAD + y - rp_lo) * W + x;   // tap (kh,kw) -> q0 + kh*W + kw - 1
+    q0[i] = m - mstart + 1;                       // tap (kh,kw) -> q0 + (kh-1)*W + kw - 1
     edgeL[i] = x == 0;
     edgeR[i] = x == W - 1;
+    edgeT[i] = y == 0;
+    edgeB[i] = y == H - 1;
   }
   const int sw_w = (r >> 1) & 7;
   int rdw[4], ck[4];
@@ -621,13 +603,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
 #endif
       const int kh = tap / 3, kw = tap - kh * 3;
-      const int toff = kh * W + kw - 1;
+      const int toff = (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
       int abase[MTW], asw[MTW];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        const bool off_row = (kw == 0 && edgeL[i]) || (kw == 2 && edgeR[i]);
-        const int q = off_row ? 0 : q0[i] + toff;   // slot 0 = zeros
+        const bool off_img = (kw == 0 && edgeL[i]) || (kw == 2 && edgeR[i]) || (kh == 0 && edgeT[i]) ||
+                             (kh == 2 && edgeB[i]);
+        const int q = off_img ? 0 : q0[i] + toff;   // slot 0 = zeros
         abase[i] = q << 7;
         asw[i] = ((q >> 1) & 7) << 4;
       }
@@ -1242,9 +1225,9 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int BN = COUT >= 128 ? 128 : 64;
     // 256-pixel tiles (each wave 128 px x 64 ch: 0.75 LDS reads per MFMA, half the weight DMA per
     // FLOP) wherever the band still leaves room for two workgroups per CU; else 128
-    constexpr int A256 = ((halo_rows_max<HI, WI, 256>() * WI + 2 + 7) / 8) * 1024;
+    constexpr int A256 = halo_band_pieces(WI, 256) * 1024;
     constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
-    constexpr int A_BYTES = ((halo_rows_max<HI, WI, BM>() * WI + 2 + 7) / 8) * 1024;
+    constexpr int A_BYTES = halo_band_pieces(WI, BM) * 1024;
     constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;  // deepest ring that keeps 2 workgroups/CU
     constexpr int LDS = A_BYTES + NSW * BN * 128;
     auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32>;

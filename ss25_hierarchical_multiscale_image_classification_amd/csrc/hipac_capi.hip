@@ -263,7 +263,35 @@ using namespace hipac;
 
 struct hipac_weights {
   Net net;
+  // Second launch lane of hipac_resnet18_forward (created at pack time, never blocking):
+  // large batches are split in two halves that run concurrently, one on the caller's stream
+  // and one here, so the tail of every launch (partly filled last round of workgroups) is
+  // covered by the other lane's kernels.  Fork / join with the caller's stream by events.
+  hipStream_t lane_stream = nullptr;
 };
+
+// Split of one forward call into lanes.  Each lane owns a whole workspace plan.
+struct Lanes {
+  int n;        // 1 or 2
+  int chunk;    // images handled by lane 0 (lane 1 takes the rest)
+  Plan p;       // per-lane plan (sized for `chunk` images)
+  size_t total; // workspace bytes
+};
+static Lanes make_lanes(int batch, int precision) {
+  Lanes L;
+  const Plan single = make_plan(batch, precision);
+  const int want = env_int("HIPAC_LANES", 2, 1, 2);
+  L.n = (want == 2 && batch >= 4 * single.bc) ? 2 : 1;
+  if (L.n == 1) {
+    L.chunk = batch, L.p = single, L.total = single.total;
+    return L;
+  }
+  L.chunk = ((batch + 1) / 2 + single.bc - 1) / single.bc * single.bc;  // whole sub-batches in lane 0
+  L.p = make_plan(L.chunk, precision);
+  // run_ops / tap address the workspace with the single-lane plan of `batch`: keep room for it
+  L.total = 2 * L.p.total > single.total ? 2 * L.p.total : single.total;
+  return L;
+}
 
 extern "C" {
 
@@ -280,6 +308,7 @@ void hipac_weights_free(hipac_weights_t* w) {
   if (w->net.fc_b) (void)hipFree(w->net.fc_b);
   if (w->net.zero_page) (void)hipFree(w->net.zero_page);
   if (w->net.lut_t) (void)hipFree(w->net.lut_t);
+  if (w->lane_stream) (void)hipStreamDestroy(w->lane_stream);
   delete w;
 }
 
@@ -332,6 +361,8 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     hipac_weights_free(w);
     return rc;
   }
+  // optional: without it forward simply runs single-lane
+  if (hipStreamCreateWithFlags(&w->lane_stream, hipStreamNonBlocking) != hipSuccess) w->lane_stream = nullptr;
   *out = w;
   return 0;
 }
@@ -341,7 +372,7 @@ int hipac_weights_num_classes(const hipac_weights_t* w) { return w ? w->net.num_
 
 size_t hipac_resnet18_workspace_bytes(int batch, int precision) {
   if (batch <= 0) return 0;
-  return make_plan(batch, precision).total;
+  return make_lanes(batch, precision).total;
 }
 
 int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, int in_layout, float* feats,
@@ -354,43 +385,70 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
                 "forward: logits/labels requested but the weights carry no fc (fc = Identity)");
   HIPAC_REQUIRE(((uintptr_t)workspace & 255) == 0, HIPAC_EINVAL, "forward: workspace must be 256-byte aligned");
   HIPAC_REQUIRE(((uintptr_t)x & 15) == 0, HIPAC_EINVAL, "forward: x must be 16-byte aligned");
-  Plan p = make_plan(batch, w->net.precision);
-  HIPAC_REQUIRE(workspace_bytes >= p.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
-                workspace_bytes, p.total);
+  const Lanes L = make_lanes(batch, w->net.precision);
+  Plan p = L.p;
+  HIPAC_REQUIRE(workspace_bytes >= L.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
+                workspace_bytes, L.total);
   HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem, HIPAC_EUNSUPPORTED,
                 "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0)");
   p.u8_input = in_layout == HIPAC_IN_U8_HWC;
-  hipStream_t s = (hipStream_t)stream;
-  char* ws = (char*)workspace;
   const Net& net = w->net;
   const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * p.esz;
   auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
                : net.precision == HIPAC_PREC_FP16 ? run_trunk_f16 : run_trunk_f32;
-  for (int g0 = 0; g0 < batch; g0 += p.gc) {
-    const int gn = batch - g0 < p.gc ? batch - g0 : p.gc;
-    for (int b0 = 0; b0 < gn; b0 += p.bc) {
-      const int bn = gn - b0 < p.bc ? gn - b0 : p.bc;
-      const void* xin = ws + p.xin;
-      if (in_layout == HIPAC_IN_NCHW_F32) {
-        int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
-                                      net.precision, s);
-        HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
-      } else if (in_layout == HIPAC_IN_U8_HWC) {
-        xin = (const char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3;  // raw patches, normalise fused in the stem
-      } else {
-        xin = (const char*)x + (size_t)(g0 + b0) * in_img_bytes;  // native layout: stem reads the caller's buffer
+  // images [i0, i0 + n) on stream s with the lane's own workspace
+  auto run_lane = [&](char* ws, int i0, int n, hipStream_t s) -> int {
+    for (int g0 = i0; g0 < i0 + n; g0 += p.gc) {
+      const int gn = i0 + n - g0 < p.gc ? i0 + n - g0 : p.gc;
+      for (int b0 = 0; b0 < gn; b0 += p.bc) {
+        const int bn = gn - b0 < p.bc ? gn - b0 : p.bc;
+        const void* xin = ws + p.xin;
+        if (in_layout == HIPAC_IN_NCHW_F32) {
+          int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
+                                        net.precision, s);
+          HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
+        } else if (in_layout == HIPAC_IN_U8_HWC) {
+          xin = (const char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3;  // raw patches, normalise fused in the stem
+        } else {
+          xin = (const char*)x + (size_t)(g0 + b0) * in_img_bytes;  // native layout: stem reads the caller's buffer
+        }
+        int rc = trunk(net, p, ws, xin, bn, b0, 0, s, 0, kNumEarlyOps - 1);
+        if (rc) return rc;
       }
-      int rc = trunk(net, p, ws, xin, bn, b0, 0, s, 0, kNumEarlyOps - 1);
+      int rc = trunk(net, p, ws, nullptr, 0, 0, gn, s, kNumEarlyOps, kNumOps - 1);
       if (rc) return rc;
+      rc = launch_head((const float*)(ws + p.blk[7]), gn, net.fc_w, net.fc_b, net.num_classes,
+                       feats ? feats + (size_t)g0 * 512 : nullptr,
+                       logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s);
+      HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
     }
-    int rc = trunk(net, p, ws, nullptr, 0, 0, gn, s, kNumEarlyOps, kNumOps - 1);
-    if (rc) return rc;
-    rc = launch_head((const float*)(ws + p.blk[7]), gn, net.fc_w, net.fc_b, net.num_classes,
-                     feats ? feats + (size_t)g0 * 512 : nullptr,
-                     logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s);
-    HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
+    return 0;
+  };
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  if (L.n == 1 || !w->lane_stream) return run_lane(ws, 0, batch, s);
+  // fork: lane 1 (the handle's stream) starts after everything already queued on s
+  hipEvent_t fork = nullptr, join = nullptr;
+  HIPAC_CHECK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  hipError_t e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    (void)hipEventDestroy(fork);
+    HIPAC_CHECK_HIP(e);
   }
-  return 0;
+  int rc = 0;
+  e = hipEventRecord(fork, s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(w->lane_stream, fork, 0);
+  if (e == hipSuccess) {
+    rc = run_lane(ws + L.p.total, L.chunk, batch - L.chunk, w->lane_stream);
+    // join even after a failed launch so the caller's stream stays ordered behind lane 1
+    e = hipEventRecord(join, w->lane_stream);
+    if (rc == 0) rc = run_lane(ws, 0, L.chunk, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, join, 0);
+  }
+  (void)hipEventDestroy(fork);  // released by the runtime once the recorded work has completed
+  (void)hipEventDestroy(join);
+  HIPAC_CHECK_HIP(e);
+  return rc;
 }
 
 int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layout, void* workspace,

@@ -153,6 +153,33 @@ def test_sub_batching_and_determinism(monkeypatch):
     assert torch.equal(f_all[5:6], f_one)
 
 
+def test_two_lane_forward_is_bit_identical(monkeypatch):
+    # batches >= 4 sub-batches are split in two halves that run concurrently (caller's stream +
+    # the handle's own stream, fork/join by events).  Same kernels, same per-image arithmetic:
+    # results must equal the single-lane run bit for bit, also when consumed right away.
+    monkeypatch.setenv("HIPAC_SUBBATCH", "16")
+    monkeypatch.setenv("HIPAC_GROUP", "32")
+    sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    u8 = synth.synth_patches_u8(150, seed=21, device="cuda")
+    net = capi.PackedResNet18(sd, precision="bf16")
+    side = torch.cuda.Stream()
+    outs = []
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("HIPAC_LANES", lanes)
+        f, l, lab = net.forward(u8, want_logits=True, want_labels=True)
+        outs.append((f.clone(), l.clone(), lab.clone(), float(f.sum())))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+    # on a non-default caller stream, back to back, with a consumer queued right behind
+    monkeypatch.setenv("HIPAC_LANES", "2")
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            f, l, lab = net.forward(u8, want_logits=True, want_labels=True)
+            chk = f.double().sum()
+        side.synchronize()
+    assert torch.equal(f, outs[0][0]) and float(chk) == float(outs[0][0].double().sum())
+
+
 def test_feature_only_handle_and_error_paths():
     sd = synth.seeded_resnet18_state_dict(0, num_classes=None)
     net = capi.PackedResNet18(sd, precision="fp16")
