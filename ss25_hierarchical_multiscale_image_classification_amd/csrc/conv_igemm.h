@@ -581,6 +581,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // residual of the epilogue's 64-pixel parts, prefetched into registers: part 0 behind the
+  // MFMAs of the last K step, part p+1 behind the staging of part p (two register sets)
+  constexpr int CPR = BN / 8;                       // 8-channel items per pixel row
+  constexpr int ITEMS = 64 * CPR;
+  constexpr int IPT = ITEMS / 256;                  // items per thread and part
+  static_assert(ITEMS % 256 == 0, "epilogue items");
+  frag rv[2][RESID ? IPT : 1];
+  auto load_resid = [&](auto PART) {
+    constexpr int part = decltype(PART)::value;
+    if constexpr (RESID) {
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        const int item = tid + 256 * k;
+        const int px = item / CPR, c8 = item - px * CPR;
+        const int m = m0 + part * 64 + px;
+        frag z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (T)0.f;
+        rv[part & 1][k] = m < M ? *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + n0 + c8 * 8) : z;
+      }
+    }
+  };
+
   issue_band(0);
 #pragma unroll
   for (int pstep = 0; pstep < NSW - 1; ++pstep)
@@ -602,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 #ifndef HIPAC_ABL_NO_W_DMA
       if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
 #endif
+      if (RESID && s == NSTEP - 1) load_resid(std::integral_constant<int, 0>{});
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
@@ -662,11 +686,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   // ---- epilogue through LDS: BM/64 parts of 64 pixels ------------------------------------
   // phase 1 (the two waves owning the half): accumulators -> fp32 [64 px][BN] rows of SROW B
   // phase 2 (all threads): + bias (+ residual) (ReLU) -> 16 B of T (32 B of fp32) per item
-  constexpr int CPR = BN / 8;                       // 8-channel items per pixel row
-  constexpr int ITEMS = 64 * CPR;
   unsigned char* const Sl = ring;
-#pragma unroll
-  for (int part = 0; part < BM / 64; ++part) {
+  static_for<BM / 64>([&](auto PART) {
+    constexpr int part = decltype(PART)::value;
+    if constexpr (part + 1 < BM / 64) load_resid(std::integral_constant<int, part + 1>{});
     __builtin_amdgcn_s_barrier();  // K loop reads (part 0) / the previous part's phase 2 are done
     if (wm == part / (MTW / 2)) {  // the two waves (wn = 0,1) that own these 64 pixels
 #pragma unroll
@@ -686,7 +709,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int item = tid; item < ITEMS; item += 256) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const int item = tid + 256 * k;
       const int px = item / CPR, c8 = item - px * CPR;
       const int m = m0 + part * 64 + px;
       if (m < M) {
@@ -699,9 +724,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
                       hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
         const size_t o = (size_t)m * COUT + c0;
         if constexpr (RESID) {
-          const frag rv = *reinterpret_cast<const frag*>(resid + o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[part & 1][k][e];
         }
         if constexpr (RELU) {
 #pragma unroll
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
         }
       }
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1004,8 +1028,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   constexpr int H_BYTES = HPIECES * 1024;
   constexpr int SROW = 272;                        // staging row: 64 fp32 + 16 B pad
   constexpr int S_BYTES = 128 * SROW;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * H_BYTES + S_BYTES];
-  unsigned char* const Sl = smem + 2 * H_BYTES;
+  constexpr int R_BYTES = RESID ? 128 * 128 : 0;   // residual tile of the unit, item-linear (16 B per item)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * H_BYTES + R_BYTES + S_BYTES];
+  unsigned char* const Rl = smem + 2 * H_BYTES;
+  unsigned char* const Sl = smem + 2 * H_BYTES + R_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1049,6 +1075,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
     }
   };
 
+  // epilogue item (tid + 256*pass) of unit u -> element offset of its 8 channels (or -1)
+  auto item_offset = [&](int u, int pass) -> long long {
+    const int item = tid + 256 * pass;
+    const int px = item >> 3, c8 = item & 7;     // px 0..127: tile px>>6, pixel px&63
+    const int tile = 2 * u + (px >> 6);
+    if (tile >= n_tiles) return -1;
+    const int b = tile / TPI, t = tile - b * TPI;
+    const int ty = t / 7, tx = t - ty * 7;
+    const int y = ty * 8 + ((px & 63) >> 3), x = tx * 8 + (px & 7);
+    return ((((long long)b * H + y) * W + x) * C + c8 * 8);
+  };
+  // LDS-DMA of the unit's residual tile: every lane fetches exactly the 16 bytes it will add in
+  // phase 2 (item-linear, so the wave's destination is one contiguous KB) -- issued at the top
+  // of the unit, it lands behind the 72 MFMAs; no cross-lane dependency, only the lane's vmcnt
+  auto issue_resid = [&](int u) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const long long o = item_offset(u, pass);
+      const char* src = o >= 0 ? reinterpret_cast<const char*>(resid) + o * 2 : zero_page + dchunk * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Rl + pass * 4096 + wave * 1024), 16, 0, 0);
+    }
+  };
+
   // this lane's two output pixels inside its tile: sub-tile i = rows 4i..4i+3; (ly,lx) = (4i + r/8, r%8)
   int lx = r & 7, ly0 = r >> 3;
   const unsigned char* const Hl = smem + wt * H_BYTES;
@@ -1059,6 +1108,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   for (; u < n_units; u += gridDim.x) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // both halos landed (and the previous unit's epilogue is finished)
+    if constexpr (RESID) issue_resid(u);
 
     // keep the 18 tap address bases from being hoisted out of the unit loop (they would
     // cost 18 VGPRs next to 144 of weights): make their inputs opaque per iteration
@@ -1091,7 +1141,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the halos: start the next unit's DMA
-    if (u + (int)gridDim.x < n_units) issue_unit(u + gridDim.x);
+    const bool more = u + (int)gridDim.x < n_units;
+    if (more) issue_unit(u + gridDim.x);
 
     // phase 1: accumulators -> fp32 staging tile [pixel = wt*64 + 32i + r][channel]
 #pragma unroll
@@ -1107,23 +1158,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // raw barrier: a __syncthreads() here would drain the DMA in flight
+    if constexpr (RESID) {
+      // this lane's residual pieces have landed once only the next unit's halo DMAs (issued
+      // later, in order: 7 per wave for waves 0-1, 6 for waves 2-3) are still outstanding
+      if (!more) wait_vmcnt<0>();
+      else if (wave < 2) wait_vmcnt<7>();
+      else wait_vmcnt<6>();
+    }
     // phase 2: + bias (+ residual) ReLU -> T, whole pixel rows: 8 lanes x 16 B per pixel
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int item = tid + 256 * pass;
-      const int px = item >> 3, c8 = item & 7;     // px 0..127: tile px>>6, pixel px&63
-      const int tile = 2 * u + (px >> 6);
-      if (tile < n_tiles) {
-        const int b = tile / TPI, t = tile - b * TPI;
-        const int ty = t / 7, tx = t - ty * 7;
-        const int y = ty * 8 + ((px & 63) >> 3), x = tx * 8 + (px & 7);
-        const size_t o = ((((size_t)b * H + y) * W + x) * C + c8 * 8);
+      const int px = item >> 3, c8 = item & 7;
+      const long long o = item_offset(u, pass);
+      if (o >= 0) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32 + 16);
         float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
                       hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
         if constexpr (RESID) {
-          const frag rv = *reinterpret_cast<const frag*>(resid + o);
+          const frag rv = *reinterpret_cast<const frag*>(Rl + item * 16);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
         }
