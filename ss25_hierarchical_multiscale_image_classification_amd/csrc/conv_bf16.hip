@@ -6,3 +6,14 @@ int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int
   return run_trunk<__bf16>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
 }
 }  // namespace hipac
+
+#ifdef HIPAC_HALO_STAMPS
+extern "C" int hipac_debug_halo_stamps(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hipac::g_halo_stamps), 64) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hipac::g_halo_stamps), z, 64) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -229,11 +229,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// PROJ (3x3 / stride 2 layers only): the BasicBlock's 1x1 / stride 2 projection shortcut reads
+// exactly the centre tap of this convolution, so it rides along as CC extra K tiles (centre-tap
+// activation tile x projection weights) into a second accumulator set and leaves through a
+// second epilogue (bias only, no ReLU) into `outp_p`: one launch, one pass over the input.
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
-          bool RELU, bool RESID, bool OUTF32>
+          bool RELU, bool RESID, bool OUTF32, bool PROJ = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
     const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
-    const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page) {
+    const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page,
+    const T* __restrict__ wgt_p = nullptr, const float* __restrict__ bias_p = nullptr,
+    void* __restrict__ outp_p = nullptr) {
   using E = Elem<T>;
   using frag = typename E::frag;
   constexpr int PAD = KS / 2;
@@ -242,6 +248,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
   constexpr int CC = CIN / 64;
   constexpr int KT = KS * KS * CC;
   constexpr int KTOT = KT * 64;
+  constexpr int KTP = PROJ ? KT + CC : KT;          // + the projection's K tiles
+  static_assert(!PROJ || (KS == 3 && STRIDE == 2 && !RESID && !OUTF32), "projection rides on 3x3/2 only");
   constexpr int WM = BM / 64, WN = BN / 64, NWAVES = WM * WN;
   constexpr int APW = BM / 8 / NWAVES;  // 1-KiB A pieces per wave per K tile
   constexpr int WPW = BN / 8 / NWAVES;  // 1-KiB W pieces per wave per K tile
@@ -295,20 +303,22 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
           mask |= 1u << (kh * KS + kw);
     a_mask[i] = mask;
   }
-  int w_off[WPW];
+  int w_off[WPW], wp_off[PROJ ? WPW : 1];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int row = (wave + NWAVES * i) * 8 + prow;  // row inside the BN tile
     const int schunk = dchunk ^ ((row >> 1) & 7);
     w_off[i] = ((n0 + row) * KTOT + schunk * 8) * 2;
+    if constexpr (PROJ) wp_off[i] = ((n0 + row) * CIN + schunk * 8) * 2;
   }
   const char* in_b = reinterpret_cast<const char*>(in);
   const char* w_b = reinterpret_cast<const char*>(wgt);
+  const char* wp_b = reinterpret_cast<const char*>(wgt_p);
   const char* zsrc = zero_page + dchunk * 16;
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
-  auto issue = [&](int tap, int tapoff_bytes, int kofs_bytes, int stage) {
+  auto issue = [&](int tap, int tapoff_bytes, int kofs_bytes, int stage, bool proj) {
     unsigned char* sbase = ring + stage * STAGE;
     static_for<APW>([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -318,8 +328,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
     });
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_b + (w_off[i] + kofs_bytes)),
-                                       (lptr_t)(sbase + BM * 128 + (wave + NWAVES * i) * 1024), 16, 0, 0);
+      const char* src = w_b + (w_off[i] + kofs_bytes);
+      if constexpr (PROJ) {
+        if (proj) src = wp_b + (wp_off[i] + kofs_bytes);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 128 + (wave + NWAVES * i) * 1024), 16, 0,
+                                       0);
     });
   };
 
@@ -331,35 +345,43 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
   const int a_rd0 = wm * 64 * 128;
   const int w_rd0 = BM * 128 + wn * 64 * 128;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], accp[PROJ ? 2 : 1][PROJ ? 2 : 1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if constexpr (PROJ) accp[i][j][e] = 0.f;
+      }
 
-  // issue-side tile counters (tile index ti = (kh*KS + kw)*CC + cc)
+  // issue-side tile counters (tile index ti = (kh*KS + kw)*CC + cc; then the projection's cc tiles)
   int i_kh = 0, i_kw = 0, i_cc = 0, i_t = 0;
-  auto issue_next = [&]() {
-    const int tap = i_kh * KS + i_kw;
-    issue(tap, ((i_kh * WI + i_kw) * CIN + i_cc * 64) * 2, i_t * 128, i_t % NSTAGE);
-    ++i_t;
-    if (++i_cc == CC) {
-      i_cc = 0;
-      if (++i_kw == KS) {
-        i_kw = 0;
-        ++i_kh;
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    if (PROJ && i_t >= KT) {  // centre tap (1,1), channel chunk i_t - KT, projection weights
+      const int pc = i_t - KT;
+      issue(4, ((WI + 1) * CIN + pc * 64) * 2, pc * 128, i_t % NSTAGE, true);
+    } else {
+      const int tap = i_kh * KS + i_kw;
+      issue(tap, ((i_kh * WI + i_kw) * CIN + i_cc * 64) * 2, i_t * 128, i_t % NSTAGE, false);
+      if (++i_cc == CC) {
+        i_cc = 0;
+        if (++i_kw == KS) {
+          i_kw = 0;
+          ++i_kh;
+        }
       }
     }
+    ++i_t;
   };
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
-    if (p < KT) issue_next();
+    if (p < KTP) issue_next();
 
-  for (int t = 0; t < KT; ++t) {
-    // tile t must have landed: tiles t+1 .. min(t+NSTAGE-2, KT-1) may stay in flight
-    const int ahead = (KT - 1 - t) < (NSTAGE - 2) ? (KT - 1 - t) : (NSTAGE - 2);
+  for (int t = 0; t < KTP; ++t) {
+    // tile t must have landed: tiles t+1 .. min(t+NSTAGE-2, KTP-1) may stay in flight
+    const int ahead = (KTP - 1 - t) < (NSTAGE - 2) ? (KTP - 1 - t) : (NSTAGE - 2);
     if constexpr (NSTAGE >= 4) {
       if (ahead >= 2) wait_vmcnt<2 * PPW>();
       else if (ahead == 1) wait_vmcnt<PPW>();
@@ -371,7 +393,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are in; stage (t-1)%NSTAGE is free
-    if (t + NSTAGE - 1 < KT) issue_next();
+    if (t + NSTAGE - 1 < KTP) issue_next();
     const unsigned char* st = ring + (t % NSTAGE) * STAGE;
     // fragment reads run one k16 step ahead of the MFMAs that consume them
     frag af[2][2], wf[2][2];
@@ -390,14 +412,45 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
         for (int j = 0; j < 2; ++j)
           wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(st + w_rd0 + j * 4096 + rd[kk + 1]);
       }
+      if (PROJ && t >= KT) {  // uniform: the last CC tiles feed the projection's accumulators
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+          for (int j = 0; j < 2; ++j)
+            accp[PROJ ? i : 0][PROJ ? j : 0] =
+                E::mfma(wf[kk & 1][j], af[kk & 1][i], accp[PROJ ? i : 0][PROJ ? j : 0]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     // the reads of this stage must have retired before any wave passes the next barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- projection epilogue: + bias -> NHWC store (no ReLU, no residual) -------------------
+  if constexpr (PROJ) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+          const float4 bv = *reinterpret_cast<const float4*>(bias_p + c0);
+          typename E::vec4 ov;
+          ov[0] = (T)(accp[i][j][4 * q + 0] + bv.x);
+          ov[1] = (T)(accp[i][j][4 * q + 1] + bv.y);
+          ov[2] = (T)(accp[i][j][4 * q + 2] + bv.z);
+          ov[3] = (T)(accp[i][j][4 * q + 3] + bv.w);
+          *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp_p) + (size_t)m * COUT + c0) = ov;
+        }
+    }
   }
 
   // ---- epilogue: +bias (+residual) (ReLU) -> NHWC store ---------------------------------
@@ -463,6 +516,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
 // every tap is conflict-free; edge taps read slot 0 (same address in all such lanes: an LDS
 // broadcast).  No per-piece div/mod, no pad rows: BM + 2W + 2 pixels per band.
 // ---------------------------------------------------------------------------------------
+#ifdef HIPAC_HALO_STAMPS
+// developer build: per-phase cycle totals of the halo kernel (s_memtime), summed over workgroups
+static __device__ unsigned long long g_halo_stamps[8];
+#define HALO_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define HALO_STAMP(var)
+#endif
 constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 1 + 7) / 8; }  // 8-pixel (1 KB) pieces
 
 // NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
@@ -604,10 +664,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     }
   };
 
+  HALO_STAMP(t_start);
   issue_band(0);
 #pragma unroll
   for (int pstep = 0; pstep < NSW - 1; ++pstep)
     if (pstep < NSTEP) issue_w(pstep, pstep);
+#ifdef HIPAC_HALO_STAMPS
+  unsigned long long t_first = 0;
+#endif
   int s = 0;
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0) {
@@ -621,6 +685,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       else wait_vmcnt<0>();
 #ifndef HIPAC_ABL_NO_BARRIER
       __builtin_amdgcn_s_barrier();
+#endif
+#ifdef HIPAC_HALO_STAMPS
+      if (s == 0) {
+        t_first = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      }
 #endif
 #ifndef HIPAC_ABL_NO_W_DMA
       if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
@@ -686,6 +756,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   // ---- epilogue through LDS: BM/64 parts of 64 pixels ------------------------------------
   // phase 1 (the two waves owning the half): accumulators -> fp32 [64 px][BN] rows of SROW B
   // phase 2 (all threads): + bias (+ residual) (ReLU) -> 16 B of T (32 B of fp32) per item
+  HALO_STAMP(t_loop);
   unsigned char* const Sl = ring;
   static_for<BM / 64>([&](auto PART) {
     constexpr int part = decltype(PART)::value;
@@ -744,6 +815,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       }
     }
   });
+#ifdef HIPAC_HALO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HALO_STAMP(t_end);
+  if (tid == 0) {
+    atomicAdd(&g_halo_stamps[0], t_first - t_start);  // prologue: band + first weight tile in flight
+    atomicAdd(&g_halo_stamps[1], t_loop - t_first);   // K loop
+    atomicAdd(&g_halo_stamps[2], t_end - t_loop);     // epilogue incl. store drain
+    atomicAdd(&g_halo_stamps[3], 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1312,8 +1393,38 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     const int mt8 = (n_mtiles + 7) / 8 * 8;
     dim3 grid(mt8 * (COUT / BN));
     hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out,
-                       M, n_mtiles, zero_page);
+                       M, n_mtiles, zero_page, (const T*)nullptr, (const float*)nullptr, (void*)nullptr);
   }
+  return (int)hipGetLastError();
+}
+
+#ifndef HIPAC_FUSE_PROJ
+#define HIPAC_FUSE_PROJ 1
+#endif
+
+// 3x3 / stride 2 conv (+BN+ReLU) of a down-sampling BasicBlock with its 1x1 / stride 2 projection
+// shortcut (+BN) riding along (conv_glds_kernel<..., PROJ = true>): x -> (out, out_p)
+template <typename T, int CIN, int COUT, int HI>
+static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* out, void* out_p, int n, hipStream_t s,
+                       const char* zero_page) {
+  using C = TileCfg<COUT>;
+  constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
+  constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
+  constexpr int LDS = NSTAGE * (BM + BN) * 128;
+  constexpr int HO = HI / 2;
+  const int M = n * HO * HO;
+  auto kern = conv_glds_kernel<T, CIN, COUT, HI, HI, 3, 2, BM, BN, NSTAGE, true, false, false, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int n_mtiles = (M + BM - 1) / BM;
+  const int mt8 = (n_mtiles + 7) / 8 * 8;
+  dim3 grid(mt8 * (COUT / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)nullptr, out, M,
+                     n_mtiles, zero_page, (const T*)wp.w, wp.bias, out_p);
   return (int)hipGetLastError();
 }
 
@@ -1347,12 +1458,21 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
   // block 0
-  if (ops.take()) HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, n, s, z)));
   const void* idt = x;
-  if constexpr (STRIDE != 1 || CI != CO) {
-    if (ops.take())
-      HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
+  if constexpr (STRIDE == 2 && sizeof(T) == 2 && HIPAC_FUSE_PROJ && CO <= 256) {
+    // one launch: conv1 and the projection shortcut (the op slot of the projection stays empty).
+    // Not for layer4: its second accumulator set pushes the kernel past 256 registers, i.e. to
+    // one workgroup per CU (measured 349 ns/img fused vs 132 + 37 separate).
+    if (ops.take()) HIPAC_TRY((launch_down<T, CI, CO, HI>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
+    (void)ops.take();
     idt = ds;
+  } else {
+    if (ops.take()) HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, n, s, z)));
+    if constexpr (STRIDE != 1 || CI != CO) {
+      if (ops.take())
+        HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
+      idt = ds;
+    }
   }
   if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, n, s, z)));
   // block 1
