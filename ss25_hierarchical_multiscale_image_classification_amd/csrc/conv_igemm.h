@@ -523,11 +523,16 @@ static __device__ unsigned long long g_halo_stamps[8];
 #else
 #define HALO_STAMP(var)
 #endif
+#ifndef HIPAC_HALO_GRID
+#define HIPAC_HALO_GRID 512  // persistent halo workgroups: 2 per CU x 256 CUs
+#endif
 constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 1 + 7) / 8; }  // 8-pixel (1 KB) pieces
 
 // NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
-// Epilogue: the 128 x BN fp32 tile goes through LDS in two halves of 64 pixels so that
-// global traffic is 16-byte pieces of whole pixel rows (residual loads and stores).
+// Epilogue: every wave sends its 32-pixel sub-tiles through a private fp32 staging area in LDS so
+// that global traffic is 16-byte items of contiguous channel runs (residual loads and stores)
+// with no workgroup barrier; workgroups are persistent and the next tile's band is prefetched
+// behind the epilogue.
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                               const float* __restrict__ bias,
@@ -547,12 +552,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
   constexpr int NTILES_N = COUT / BN;
   constexpr int NSTEP = 9 * CC;
-  constexpr int SROW = BN * 4 + 16;                  // epilogue staging row (fp32 + pad), bytes
   static_assert((BM == 128 || BM == 256) && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
   static_assert((BN / 8) % 4 == 0, "W piece split");
   static_assert(NSW == 2 || NSW == 3, "weight ring depth");
-  static_assert(A_BYTES + NSW * W_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
-  static_assert(64 * SROW <= A_BYTES + NSW * W_BYTES, "epilogue staging aliases the band + ring");
+  constexpr int STG_BYTES = 4 * 32 * (WTN * 4 + 16);  // 4 waves x [32 px][WTN fp32 + pad] epilogue staging
+  constexpr int S_BYTES = NSW * W_BYTES > STG_BYTES ? NSW * W_BYTES : STG_BYTES;  // ring, aliased by the staging
+  static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   unsigned char* const Abuf = ring;
@@ -564,35 +569,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   const int wm = wave % WM, wn = wave / WM;
   const int r = lane & 31, h = lane >> 5;
 
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int mt = (slot / NTILES_N) * 8 + xcd;
-  const int nt = slot % NTILES_N;
-  if (mt >= n_mtiles) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // band = the contiguous pixel range [m0 - W - 1, mlast + W + 1] of the flattened activation
-  const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
-  const int mstart = m0 - W - 1;
-  const int npx = mlast - m0 + 1 + 2 * W + 2;    // band pixels; slots 1..npx
-  const int npieces = (npx + 1 + 7) >> 3;
-
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
   const char* in_b = reinterpret_cast<const char*>(in);
   const char* w_b = reinterpret_cast<const char*>(wgt);
   const int prow = lane >> 3, dchunk = lane & 7;
 
-  auto issue_band = [&](int cc) {
-    for (int p = wave; p < npieces; p += 4) {
+  // band of the tile starting at pixel m0_: the contiguous pixel range [m0_ - W - 1, mlast_ + W + 1]
+  auto issue_band_of = [&](int m0_, int cc) {
+    const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
+    const int mstart_ = m0_ - W - 1;
+    const int npx_ = mlast_ - m0_ + 1 + 2 * W + 2;  // band pixels; slots 1..npx
+    const int npieces_ = (npx_ + 1 + 7) >> 3;
+    for (int p = wave; p < npieces_; p += 4) {
       const int q = p * 8 + prow;                // slot
-      const int mm = mstart + q - 1;             // flattened pixel held by this slot
-      const bool ok = q >= 1 && q <= npx && mm >= 0 && mm < M;
+      const int mm = mstart_ + q - 1;            // flattened pixel held by this slot
+      const bool ok = q >= 1 && q <= npx_ && mm >= 0 && mm < M;
       const int schunk = dchunk ^ ((q >> 1) & 7);
       const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
     }
   };
+
+  // Persistent workgroups: virtual block id vb = blockIdx.x + i * gridDim.x (gridDim.x % 8 == 0, so a
+  // workgroup stays on its XCD's slice of the tile order).  The band of the NEXT tile is brought
+  // in during the epilogue of the current one (the epilogue stages through the weight ring only).
+  for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
+  const int xcd = vb & 7, slot = vb >> 3;
+  const int mt = (slot / NTILES_N) * 8 + xcd;
+  const int nt = slot % NTILES_N;
+  if (mt >= n_mtiles) break;  // mt grows with vb on a fixed XCD: nothing valid follows
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
+  const int mstart = m0 - W - 1;
+  auto issue_band = [&](int cc) { issue_band_of(m0, cc); };
+  if (!first_tile) __builtin_amdgcn_s_barrier();  // the previous tile's staging reads are done: ring is free
   int w_off[WPW];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
@@ -641,31 +652,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // residual of the epilogue's 64-pixel parts, prefetched into registers: part 0 behind the
-  // MFMAs of the last K step, part p+1 behind the staging of part p (two register sets)
-  constexpr int CPR = BN / 8;                       // 8-channel items per pixel row
-  constexpr int ITEMS = 64 * CPR;
-  constexpr int IPT = ITEMS / 256;                  // items per thread and part
-  static_assert(ITEMS % 256 == 0, "epilogue items");
+  // Epilogue geometry (per WAVE, no workgroup barriers): the wave owns MTW sub-tiles of 32 pixels x
+  // WTN channels.  Sub-tile i goes through the wave's private fp32 staging [32 px][WTN] and leaves
+  // as 16-byte items (8 channels): item = lane + 64k -> pixel item / CPW, channel group lane % CPW.
+  constexpr int CPW = WTN / 8;                      // 8-channel items per pixel (wave's channel half)
+  constexpr int IPT = 32 * CPW / 64;                // items per lane and sub-tile
+  constexpr int SROWW = WTN * 4 + 16;               // staging row: WTN fp32 + pad
+  static_assert(64 % CPW == 0 && (32 * CPW) % 64 == 0, "epilogue items");
+  static_assert(4 * 32 * SROWW <= S_BYTES, "per-wave staging fits the ring region");
+  const int e_c0 = n0 + wn * WTN + (lane % CPW) * 8;  // first of this lane's 8 output channels
+  const int e_px = lane / CPW;                        // pixel of item k: e_px + k * (64 / CPW)
+  // residual, prefetched into registers: sub-tile 0 behind the MFMAs of the last K step,
+  // sub-tile i+1 behind the staging of sub-tile i (two register sets)
   frag rv[2][RESID ? IPT : 1];
-  auto load_resid = [&](auto PART) {
-    constexpr int part = decltype(PART)::value;
+  auto load_resid = [&](auto SUB) {
+    constexpr int i = decltype(SUB)::value;
     if constexpr (RESID) {
 #pragma unroll
       for (int k = 0; k < IPT; ++k) {
-        const int item = tid + 256 * k;
-        const int px = item / CPR, c8 = item - px * CPR;
-        const int m = m0 + part * 64 + px;
+        const int m = m0 + wm * (MTW * 32) + i * 32 + e_px + k * (64 / CPW);
         frag z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (T)0.f;
-        rv[part & 1][k] = m < M ? *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + n0 + c8 * 8) : z;
+        rv[i & 1][k] = m < M ? *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0) : z;
       }
     }
   };
 
   HALO_STAMP(t_start);
-  issue_band(0);
+  if (first_tile) issue_band(0);
 #pragma unroll
   for (int pstep = 0; pstep < NSW - 1; ++pstep)
     if (pstep < NSTEP) issue_w(pstep, pstep);
@@ -753,50 +768,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     }
   }
 
-  // ---- epilogue through LDS: BM/64 parts of 64 pixels ------------------------------------
-  // phase 1 (the two waves owning the half): accumulators -> fp32 [64 px][BN] rows of SROW B
-  // phase 2 (all threads): + bias (+ residual) (ReLU) -> 16 B of T (32 B of fp32) per item
   HALO_STAMP(t_loop);
-  unsigned char* const Sl = ring;
-  static_for<BM / 64>([&](auto PART) {
-    constexpr int part = decltype(PART)::value;
-    if constexpr (part + 1 < BM / 64) load_resid(std::integral_constant<int, part + 1>{});
-    __builtin_amdgcn_s_barrier();  // K loop reads (part 0) / the previous part's phase 2 are done
-    if (wm == part / (MTW / 2)) {  // the two waves (wn = 0,1) that own these 64 pixels
+  // ---- epilogue -------------------------------------------------------------------------------
+  const float4 b_lo = *reinterpret_cast<const float4*>(bias + e_c0);
+  const float4 b_hi = *reinterpret_cast<const float4*>(bias + e_c0 + 4);
+  __builtin_amdgcn_s_barrier();  // every wave has left the K loop: band and ring are free
+  {
+    // prefetch the next tile's first band chunk; it lands behind this epilogue
+    const int vn = vb + gridDim.x;
+    const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
+    if (mtn < n_mtiles) issue_band_of(mtn * BM, 0);
+  }
+  unsigned char* const Sl = Wbuf + wave * (32 * SROWW);  // this wave's private staging
+  static_for<MTW>([&](auto SUB) {
+    constexpr int i = decltype(SUB)::value;
+    if constexpr (i + 1 < MTW) load_resid(std::integral_constant<int, i + 1>{});
+    // accumulators -> fp32 rows (LDS operations of one wave complete in order: no barrier)
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = (part % (MTW / 2)) * 2 + ii;  // compile-time after unrolling
-            f32x4 v;
-            v[0] = acc[i][j][4 * q + 0];
-            v[1] = acc[i][j][4 * q + 1];
-            v[2] = acc[i][j][4 * q + 2];
-            v[3] = acc[i][j][4 * q + 3];
-            *reinterpret_cast<f32x4*>(Sl + (32 * ii + r) * SROW + (wn * WTN + j * 32 + 8 * q + 4 * h) * 4) = v;
-          }
-    }
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * q + 0];
+        v[1] = acc[i][j][4 * q + 1];
+        v[2] = acc[i][j][4 * q + 2];
+        v[3] = acc[i][j][4 * q + 3];
+        *reinterpret_cast<f32x4*>(Sl + r * SROWW + (j * 32 + 8 * q + 4 * h) * 4) = v;
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-      const int item = tid + 256 * k;
-      const int px = item / CPR, c8 = item - px * CPR;
-      const int m = m0 + part * 64 + px;
+      const int px = e_px + k * (64 / CPW);
+      const int m = m0 + wm * (MTW * 32) + i * 32 + px;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROWW + (lane % CPW) * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROWW + (lane % CPW) * 32 + 16);
       if (m < M) {
-        const int c0 = n0 + c8 * 8;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32 + 16);
-        const float4 b_lo = *reinterpret_cast<const float4*>(bias + c0);
-        const float4 b_hi = *reinterpret_cast<const float4*>(bias + c0 + 4);
         float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
                       hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
-        const size_t o = (size_t)m * COUT + c0;
+        const size_t o = (size_t)m * COUT + e_c0;
         if constexpr (RESID) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[part & 1][k][e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[i & 1][k][e];
         }
         if constexpr (RELU) {
 #pragma unroll
@@ -814,17 +826,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
         }
       }
     }
+    // the next sub-tile overwrites the staging rows: this wave's reads above must have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
 #ifdef HIPAC_HALO_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   HALO_STAMP(t_end);
   if (tid == 0) {
     atomicAdd(&g_halo_stamps[0], t_first - t_start);  // prologue: band + first weight tile in flight
     atomicAdd(&g_halo_stamps[1], t_loop - t_first);   // K loop
-    atomicAdd(&g_halo_stamps[2], t_end - t_loop);     // epilogue incl. store drain
+    atomicAdd(&g_halo_stamps[2], t_end - t_loop);     // epilogue
     atomicAdd(&g_halo_stamps[3], 1ull);
   }
 #endif
+  }  // persistent tile loop
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1364,7 +1378,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
     constexpr int A_BYTES = halo_band_pieces(WI, BM) * 1024;
     constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;  // deepest ring that keeps 2 workgroups/CU
-    constexpr int LDS = A_BYTES + NSW * BN * 128;
+    constexpr int STG = 4 * 32 * (BN / 2 * 4 + 16);  // epilogue staging, aliases the ring
+    constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
     auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1374,7 +1389,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     }
     const int n_mtiles = (M + BM - 1) / BM;
     const int mt8 = (n_mtiles + 7) / 8 * 8;
-    dim3 grid(mt8 * (COUT / BN));
+    const int n_vtiles = mt8 * (COUT / BN);
+    dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);  // persistent; both are multiples of 8
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
                        n_mtiles, zero_page);
   } else {
