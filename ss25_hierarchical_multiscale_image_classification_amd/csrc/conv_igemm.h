@@ -511,10 +511,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
 // image (x or y edge), where it reads zeros.  So the band a workgroup needs is simply the
 // CONTIGUOUS pixel range [m0 - W - 1, mlast + W + 1] (it may run into neighbouring images;
 // those pixels are never selected because the edge flags redirect such taps).  In LDS:
-// slot 0 = a pixel of zeros, slot q >= 1 = pixel m0 - W - 2 + q, [slot][64 ch] with the chunk
-// swizzle of v2 (c ^ ((q >> 1) & 7)).  Consecutive output pixels sit in consecutive slots, so
-// every tap is conflict-free; edge taps read slot 0 (same address in all such lanes: an LDS
-// broadcast).  No per-piece div/mod, no pad rows: BM + 2W + 2 pixels per band.
+// slots 0 and 1 = pixels of zeros, slot q >= 2 = pixel m0 - W - 3 + q, [slot][64 ch] with the
+// chunk swizzle of v2 (c ^ ((q >> 1) & 7)).  Consecutive output pixels sit in consecutive slots,
+// so a ds_read_b128 lane group covers all 16 bank groups of the 256-byte bank row; an edge tap
+// reads the zero slot of its own parity at its own swizzled chunk, which keeps that property
+// (measured before this: 21-29 % of LDS cycles lost to bank conflicts from a single zero slot).
+// No per-piece div/mod, no pad rows: BM + 2W + 2 pixels per band.
 // ---------------------------------------------------------------------------------------
 #ifdef HIPAC_HALO_STAMPS
 // developer build: per-phase cycle totals of the halo kernel (s_memtime), summed over workgroups
@@ -523,10 +525,13 @@ static __device__ unsigned long long g_halo_stamps[8];
 #else
 #define HALO_STAMP(var)
 #endif
+#ifndef HIPAC_HALO_W_ISSUE_KK
+#define HIPAC_HALO_W_ISSUE_KK 1  // k16 sub-step after whose MFMAs the next weight tile is requested (-1: step start)
+#endif
 #ifndef HIPAC_HALO_GRID
 #define HIPAC_HALO_GRID 512  // persistent halo workgroups: 2 per CU x 256 CUs
 #endif
-constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 1 + 7) / 8; }  // 8-pixel (1 KB) pieces
+constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) / 8; }  // 8-pixel (1 KB) pieces
 
 // NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
 // Epilogue: every wave sends its 32-pixel sub-tiles through a private fp32 staging area in LDS so
@@ -579,12 +584,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   auto issue_band_of = [&](int m0_, int cc) {
     const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
     const int mstart_ = m0_ - W - 1;
-    const int npx_ = mlast_ - m0_ + 1 + 2 * W + 2;  // band pixels; slots 1..npx
-    const int npieces_ = (npx_ + 1 + 7) >> 3;
+    const int npx_ = mlast_ - m0_ + 1 + 2 * W + 2;  // band pixels; slots 2..npx+1 (slots 0, 1 = zeros)
+    const int npieces_ = (npx_ + 2 + 7) >> 3;
     for (int p = wave; p < npieces_; p += 4) {
       const int q = p * 8 + prow;                // slot
-      const int mm = mstart_ + q - 1;            // flattened pixel held by this slot
-      const bool ok = q >= 1 && q <= npx_ && mm >= 0 && mm < M;
+      const int mm = mstart_ + q - 2;            // flattened pixel held by this slot
+      const bool ok = q >= 2 && q <= npx_ + 1 && mm >= 0 && mm < M;
       const int schunk = dchunk ^ ((q >> 1) & 7);
       const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     const int b = m / (H * W);
     const int rem = m - b * (H * W);
     const int y = rem / W, x = rem - y * W;
-    q0[i] = m - mstart + 1;                       // tap (kh,kw) -> q0 + (kh-1)*W + kw - 1
+    q0[i] = m - mstart + 2;                       // tap (kh,kw) -> q0 + (kh-1)*W + kw - 1
     edgeL[i] = x == 0;
     edgeR[i] = x == W - 1;
     edgeT[i] = y == 0;
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
         __builtin_amdgcn_s_waitcnt(0xC07F);
       }
 #endif
-#ifndef HIPAC_ABL_NO_W_DMA
+#if !defined(HIPAC_ABL_NO_W_DMA) && HIPAC_HALO_W_ISSUE_KK < 0
       if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
 #endif
       if (RESID && s == NSTEP - 1) load_resid(std::integral_constant<int, 0>{});
@@ -719,9 +724,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       for (int i = 0; i < MTW; ++i) {
         const bool off_img = (kw == 0 && edgeL[i]) || (kw == 2 && edgeR[i]) || (kh == 0 && edgeT[i]) ||
                              (kh == 2 && edgeB[i]);
-        const int q = off_img ? 0 : q0[i] + toff;   // slot 0 = zeros
+        // out-of-image taps read a zero pixel: slot 0 or 1 by the parity of the slot the lane would
+        // have read, at the chunk position its swizzle selects -- i.e. the SAME 16-byte bank group
+        // as the in-image address, so redirected lanes never collide with their neighbours
+        const int qt = q0[i] + toff;
+        const int q = off_img ? (qt & 1) : qt;
         abase[i] = q << 7;
-        asw[i] = ((q >> 1) & 7) << 4;
+        asw[i] = ((qt >> 1) & 7) << 4;
       }
       frag af[2][MTW], wf[2][NT];
 #ifdef HIPAC_ABL_NO_LDSREAD
@@ -762,6 +771,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+#if !defined(HIPAC_ABL_NO_W_DMA) && HIPAC_HALO_W_ISSUE_KK >= 0
+        // the next step's weight DMA is issued from inside the MFMA stream (its slot was freed by this
+        // step's barrier), where its issue cost hides behind queued MFMAs instead of delaying the
+        // step's first LDS reads
+        if (kk == HIPAC_HALO_W_ISSUE_KK && s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+#endif
       }
       __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
