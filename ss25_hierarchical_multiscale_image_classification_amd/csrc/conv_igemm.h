@@ -675,11 +675,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     if constexpr (RESID) {
 #pragma unroll
       for (int k = 0; k < IPT; ++k) {
-        const int m = m0 + wm * (MTW * 32) + i * 32 + e_px + k * (64 / CPW);
-        frag z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (T)0.f;
-        rv[i & 1][k] = m < M ? *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0) : z;
+        int m = m0 + wm * (MTW * 32) + i * 32 + e_px + k * (64 / CPW);
+        m = m < M ? m : M - 1;  // unconditional load from a valid row (tail rows are never stored)
+        rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0);
       }
     }
   };
@@ -1115,6 +1113,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 //   * persistent workgroups (grid-stride over work units), 4 waves
 //   * a unit = two 8x8 output tiles; each tile's 10x10 input halo (64 ch = 128 B per pixel)
 //     is brought into LDS by LDS-DMA: 200 pixels per 128 outputs = 1.56x re-read
+//   * the halos are DOUBLE-BUFFERED ACROSS UNITS: the DMA of unit u+1 is issued at the top of
+//     unit u and has the whole unit (72 MFMAs + epilogue) to land -- one workgroup barrier per unit
 //   * K = 576 is short enough for every lane to keep ITS weight fragments for all 9 taps in
 //     registers (36 fragments = 144 VGPRs; wave = one tile x 32 channels), so weights are
 //     fetched once per workgroup and LDS serves only activation fragments, with NO barrier
@@ -1122,9 +1122,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 //   * LDS placement of halo pixel (hy,hx): slot hy*10+hx, 16-byte chunk c stored at
 //     c ^ (((hx>>1)&1) | ((hy&3)<<1)).  For every tap, a ds_read_b128 lane group (4 runs of 4
 //     consecutive x on 4 consecutive rows) then hits 16 distinct 16-byte slots: conflict-free
-//   * epilogue staged through LDS as fp32 [pixel][64] so global traffic is whole 128-byte
-//     pixel rows: 16-byte coalesced residual loads and stores; the DMA of the NEXT unit's
-//     halos is issued before the epilogue and overlaps it
+//   * epilogue per WAVE (no barrier): each 32-pixel x 32-channel sub-tile goes through the
+//     wave's private fp32 staging rows and leaves as 16-byte items, 64 contiguous bytes per
+//     pixel; the residual items are prefetched into registers one sub-tile ahead
 // ---------------------------------------------------------------------------------------
 template <typename T, bool RESID>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
@@ -1136,17 +1136,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   constexpr int H = 56, W = 56, C = 64, TPI = 49;  // 7 x 7 tiles of 8 x 8 per image
   constexpr int HALO = 10, HPIECES = 13;           // 100 halo pixels -> 13 pieces of 8
   constexpr int H_BYTES = HPIECES * 1024;
-  constexpr int SROW = 272;                        // staging row: 64 fp32 + 16 B pad
-  constexpr int S_BYTES = 128 * SROW;
-  constexpr int R_BYTES = RESID ? 128 * 128 : 0;   // residual tile of the unit, item-linear (16 B per item)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * H_BYTES + R_BYTES + S_BYTES];
-  unsigned char* const Rl = smem + 2 * H_BYTES;
-  unsigned char* const Sl = smem + 2 * H_BYTES + R_BYTES;
+  constexpr int U_BYTES = 2 * H_BYTES;             // the two halos of a unit
+  constexpr int SROW = 144;                        // staging row: 32 fp32 + 16 B pad
+  constexpr int SW_BYTES = 32 * SROW;              // one wave's staging (one sub-tile)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * U_BYTES + 4 * SW_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wt = wave & 1, wn = wave >> 1;  // tile of the pair, channel half
   const int r = lane & 31, h = lane >> 5;
+  unsigned char* const Sl = smem + 2 * U_BYTES + wave * SW_BYTES;
 
   // weights of channels wn*32 + r, all 9 taps x 64 input channels, in registers
   frag wreg[9][4];
@@ -1157,72 +1156,115 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) wreg[tap][kk] = *reinterpret_cast<const frag*>(wb + tap * 128 + kk * 32);
   }
-  // bias of the 8 channels this thread finalises in the epilogue (item -> c8 = tid & 7 in every pass)
-  const float4 b_lo = *reinterpret_cast<const float4*>(bias + (tid & 7) * 8);
-  const float4 b_hi = *reinterpret_cast<const float4*>(bias + (tid & 7) * 8 + 4);
+  // epilogue item k of a sub-tile: pixel e_px + 16k (0..31), channels wn*32 + e_c8*8 .. +7
+  const int e_c8 = lane & 3, e_px = lane >> 2;
+  const float4 b_lo = *reinterpret_cast<const float4*>(bias + wn * 32 + e_c8 * 8);
+  const float4 b_hi = *reinterpret_cast<const float4*>(bias + wn * 32 + e_c8 * 8 + 4);
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
   const int prow = lane >> 3, dchunk = lane & 7;
   const char* in_b = reinterpret_cast<const char*>(in);
 
-  // LDS-DMA of the two halos of unit u (tiles 2u, 2u+1); 26 pieces over 4 waves
-  auto issue_unit = [&](int u) {
-    for (int p = wave; p < 2 * HPIECES; p += 4) {
-      const int tsel = p >= HPIECES ? 1 : 0;
-      const int pp = p - tsel * HPIECES;
+  // LDS-DMA of the two halos of unit u (tiles 2u, 2u+1) into buffer `buf`; 26 pieces over 4 waves.
+  // Everything about a piece that does not depend on the tile is computed once: the byte offset of
+  // this lane's 16 bytes relative to the tile's first pixel, with 4 edge bits in its low nibble
+  // (halo row 0 / row 9 / column 0 / column 9), so a unit costs a handful of VALU per piece.
+  // Slots 100..103 of a halo do not exist: they re-fetch pixel 99 (never read).
+  constexpr int NPW = (2 * HPIECES + 3) / 4;  // pieces per wave (7; waves 2, 3 have 6)
+  int piece_pk[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int p = wave + 4 * k;
+    const int pp = p >= HPIECES ? p - HPIECES : p;
+    int q = pp * 8 + prow;
+    q = q < HALO * HALO ? q : HALO * HALO - 1;
+    const int hy = q / HALO, hx = q - hy * HALO;
+    const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
+    const int rel = ((hy - 1) * W + (hx - 1)) * (C * 2) + (dchunk ^ sw) * 16;
+    piece_pk[k] = rel | (hy == 0 ? 1 : 0) | (hy == HALO - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HALO - 1 ? 8 : 0);
+  }
+  auto issue_unit = [&](int u, int buf) {
+    const char* tbase[2];
+    int tmask[2];
+#pragma unroll
+    for (int tsel = 0; tsel < 2; ++tsel) {  // wave-uniform tile scalars
       const int tile = 2 * u + tsel;
-      const int q = pp * 8 + prow;             // halo pixel slot 0..103 (>= 100: unused)
-      const int hy = q / HALO, hx = q - hy * HALO;
       const int b = tile / TPI, t = tile - b * TPI;
       const int ty = t / 7, tx = t - ty * 7;
-      const int y = ty * 8 + hy - 1, x = tx * 8 + hx - 1;
-      const bool ok = tile < n_tiles && q < HALO * HALO && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-      const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
-      const char* src = ok ? in_b + ((((size_t)b * H + y) * W + x) * C + (dchunk ^ sw) * 8) * 2
-                           : zero_page + dchunk * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + tsel * H_BYTES + pp * 1024), 16, 0, 0);
+      tbase[tsel] = in_b + (((size_t)b * H + ty * 8) * W + tx * 8) * (C * 2);
+      // bit 4: the tile lies beyond the batch -> every piece reads zeros
+      tmask[tsel] = tile < n_tiles ? ((ty == 0 ? 1 : 0) | (ty == 6 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == 6 ? 8 : 0)) : 16;
     }
-  };
-
-  // epilogue item (tid + 256*pass) of unit u -> element offset of its 8 channels (or -1)
-  auto item_offset = [&](int u, int pass) -> long long {
-    const int item = tid + 256 * pass;
-    const int px = item >> 3, c8 = item & 7;     // px 0..127: tile px>>6, pixel px&63
-    const int tile = 2 * u + (px >> 6);
-    if (tile >= n_tiles) return -1;
-    const int b = tile / TPI, t = tile - b * TPI;
-    const int ty = t / 7, tx = t - ty * 7;
-    const int y = ty * 8 + ((px & 63) >> 3), x = tx * 8 + (px & 7);
-    return ((((long long)b * H + y) * W + x) * C + c8 * 8);
-  };
-  // LDS-DMA of the unit's residual tile: every lane fetches exactly the 16 bytes it will add in
-  // phase 2 (item-linear, so the wave's destination is one contiguous KB) -- issued at the top
-  // of the unit, it lands behind the 72 MFMAs; no cross-lane dependency, only the lane's vmcnt
-  auto issue_resid = [&](int u) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const long long o = item_offset(u, pass);
-      const char* src = o >= 0 ? reinterpret_cast<const char*>(resid) + o * 2 : zero_page + dchunk * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Rl + pass * 4096 + wave * 1024), 16, 0, 0);
-    }
+    static_for<NPW>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const int p = wave + 4 * k;
+      if (p < 2 * HPIECES) {
+        const int tsel = p >= HPIECES ? 1 : 0;
+        const int pp = p - tsel * HPIECES;
+        const int tm = tmask[tsel];
+        const bool ok = tm != 16 && (piece_pk[k] & tm & 15) == 0;
+        const char* src = ok ? tbase[tsel] + (piece_pk[k] & ~15) : zero_page + dchunk * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * U_BYTES + tsel * H_BYTES + pp * 1024),
+                                         16, 0, 0);
+      }
+    });
   };
 
   // this lane's two output pixels inside its tile: sub-tile i = rows 4i..4i+3; (ly,lx) = (4i + r/8, r%8)
   int lx = r & 7, ly0 = r >> 3;
-  const unsigned char* const Hl = smem + wt * H_BYTES;
 
   const int n_units = (n_tiles + 1) >> 1;
   int u = blockIdx.x;
-  if (u < n_units) issue_unit(u);
-  for (; u < n_units; u += gridDim.x) {
+  // the weight / bias loads above must retire BEFORE the unit loop: otherwise the compiler drains
+  // vmcnt -- and with it the prefetched DMA of the next unit -- in front of the first MFMA of
+  // every unit (seen in the RESID variant: s_waitcnt vmcnt(0) right after s_setprio 1)
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(wreg[tap][kk]));  // a use: forces the wait here
+  asm volatile("" ::"v"(b_lo.x), "v"(b_hi.x));
+  if (u < n_units) issue_unit(u, 0);
+#ifdef HIPAC_HALO_STAMPS
+  unsigned long long c_sum[5] = {0, 0, 0, 0, 0};
+#endif
+  for (int it = 0; u < n_units; u += gridDim.x, ++it) {
+    const int buf = it & 1;
+    HALO_STAMP(c_t0);
     wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // both halos landed (and the previous unit's epilogue is finished)
-    if constexpr (RESID) issue_resid(u);
+    HALO_STAMP(c_t0b);
+    __builtin_amdgcn_s_barrier();  // halos of this unit landed; every wave is past its reads of the other buffer
+    HALO_STAMP(c_t1);
+
+    // this wave's tile and the element offset of its epilogue items (pixel e_px + 16k of sub-tile i)
+    const bool tile_ok = 2 * u + wt < n_tiles;
+    const int tile = tile_ok ? 2 * u + wt : n_tiles - 1;  // addresses stay inside the tensors; stores are guarded
+    const int tb = tile / TPI, tt = tile - tb * TPI;
+    const int ty = tt / 7, tx = tt - ty * 7;
+    // pixel (4i + (e_px + 16k) / 8, (e_px + 16k) % 8) of the tile -> NHWC element offset
+    auto item_off = [&](int i, int k) -> size_t {
+      const int px = e_px + 16 * k;
+      const int y = ty * 8 + 4 * i + (px >> 3), x = tx * 8 + (px & 7);
+      return (((size_t)tb * H + y) * W + x) * C + wn * 32 + e_c8 * 8;
+    };
+    frag rv[2][RESID ? 2 : 1];
+    auto load_resid = [&](auto SUB) {
+      constexpr int i = decltype(SUB)::value;
+      if constexpr (RESID) {
+        // unconditional loads (no select, no branch): a conditional one makes the compiler drain
+        // vmcnt -- and with it the next unit's DMA -- right here instead of at the first use
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const frag*>(resid + item_off(i, k));
+      }
+    };
+    load_resid(std::integral_constant<int, 0>{});  // ahead of the DMA below: vmcnt retires in issue order
+    load_resid(std::integral_constant<int, 1>{});
+    if (u + (int)gridDim.x < n_units) issue_unit(u + gridDim.x, buf ^ 1);  // lands behind this whole unit
 
     // keep the 18 tap address bases from being hoisted out of the unit loop (they would
     // cost 18 VGPRs next to 144 of weights): make their inputs opaque per iteration
     asm volatile("" : "+v"(lx), "+v"(ly0));
+    const unsigned char* const Hl = smem + buf * U_BYTES + wt * H_BYTES;
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1249,14 +1291,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done with the halos: start the next unit's DMA
-    const bool more = u + (int)gridDim.x < n_units;
-    if (more) issue_unit(u + gridDim.x);
+    HALO_STAMP(c_t2);
 
-    // phase 1: accumulators -> fp32 staging tile [pixel = wt*64 + 32i + r][channel]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    // epilogue, per wave: sub-tile i -> private fp32 rows -> + bias (+ residual) ReLU -> T
+    static_for<2>([&](auto SUB) {
+      constexpr int i = decltype(SUB)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
@@ -1264,40 +1303,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
         v[1] = acc[i][4 * q + 1];
         v[2] = acc[i][4 * q + 2];
         v[3] = acc[i][4 * q + 3];
-        *reinterpret_cast<f32x4*>(Sl + (wt * 64 + 32 * i + r) * SROW + (wn * 32 + 8 * q + 4 * h) * 4) = v;
+        *reinterpret_cast<f32x4*>(Sl + r * SROW + (8 * q + 4 * h) * 4) = v;
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // raw barrier: a __syncthreads() here would drain the DMA in flight
-    if constexpr (RESID) {
-      // this lane's residual pieces have landed once only the next unit's halo DMAs (issued
-      // later, in order: 7 per wave for waves 0-1, 6 for waves 2-3) are still outstanding
-      if (!more) wait_vmcnt<0>();
-      else if (wave < 2) wait_vmcnt<7>();
-      else wait_vmcnt<6>();
-    }
-    // phase 2: + bias (+ residual) ReLU -> T, whole pixel rows: 8 lanes x 16 B per pixel
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave's LDS operations complete in order
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int item = tid + 256 * pass;
-      const int px = item >> 3, c8 = item & 7;
-      const long long o = item_offset(u, pass);
-      if (o >= 0) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + c8 * 32 + 16);
+      for (int k = 0; k < 2; ++k) {
+        const int px = e_px + 16 * k;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32 + 16);
         float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
                       hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
         if constexpr (RESID) {
-          const frag rv = *reinterpret_cast<const frag*>(Rl + item * 16);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][k][e];
         }
         frag ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ov[e] = (T)fmaxf(v[e], 0.f);
-        *reinterpret_cast<frag*>(out + o) = ov;
+        if (tile_ok) *reinterpret_cast<frag*>(out + item_off(i, k)) = ov;
       }
-    }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads returned before it is overwritten
+    });
+#ifdef HIPAC_HALO_STAMPS
+    HALO_STAMP(c_t3);
+    c_sum[0] += c_t0b - c_t0;  // vmcnt drain (DMA of this unit + own stores)
+    c_sum[1] += c_t1 - c_t0b;  // barrier
+    c_sum[2] += c_t2 - c_t1;   // DMA issue + 72 MFMAs
+    c_sum[3] += c_t3 - c_t2;   // epilogue
+    c_sum[4] += 1;
+#endif
   }
+#ifdef HIPAC_HALO_STAMPS
+  if (lane == 0) {
+    atomicAdd(&g_halo_stamps[4], c_sum[0]);
+    atomicAdd(&g_halo_stamps[5], c_sum[1]);
+    atomicAdd(&g_halo_stamps[6], c_sum[2]);
+    atomicAdd(&g_halo_stamps[7], c_sum[3]);
+    atomicAdd(&g_halo_stamps[3], c_sum[4]);
+  }
+#endif
 }
 
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
