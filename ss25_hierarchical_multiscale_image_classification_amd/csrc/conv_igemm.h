@@ -525,6 +525,9 @@ static __device__ unsigned long long g_halo_stamps[8];
 #else
 #define HALO_STAMP(var)
 #endif
+#ifndef HIPAC_C64_PF
+#define HIPAC_C64_PF 2  // layer1 kernel: LDS fragment reads run this many k16 steps ahead of their MFMAs
+#endif
 #ifndef HIPAC_HALO_W_ISSUE_KK
 #define HIPAC_HALO_W_ISSUE_KK 1  // k16 sub-step after whose MFMAs the next weight tile is requested (-1: step start)
 #endif
@@ -1138,14 +1141,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   constexpr int H_BYTES = HPIECES * 1024;
   constexpr int U_BYTES = 2 * H_BYTES;             // the two halos of a unit
   constexpr int SROW = 144;                        // staging row: 32 fp32 + 16 B pad
-  constexpr int SW_BYTES = 32 * SROW;              // one wave's staging (one sub-tile)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * U_BYTES + 4 * SW_BYTES];
+  constexpr int SPX = RESID ? 16 : 32;             // pixels staged at a time (RESID: LDS also holds the residual)
+  constexpr int SW_BYTES = SPX * SROW;             // one wave's staging
+  constexpr int R_BYTES = RESID ? 4 * 4096 : 0;    // residual of the unit: per wave 2 sub-tiles x 32 px x 64 B
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * U_BYTES + R_BYTES + 4 * SW_BYTES + 64 * 4];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wt = wave & 1, wn = wave >> 1;  // tile of the pair, channel half
   const int r = lane & 31, h = lane >> 5;
-  unsigned char* const Sl = smem + 2 * U_BYTES + wave * SW_BYTES;
+  unsigned char* const Rl = smem + 2 * U_BYTES + wave * 4096;
+  unsigned char* const Sl = smem + 2 * U_BYTES + R_BYTES + wave * SW_BYTES;
+  float* const Bl = reinterpret_cast<float*>(smem + 2 * U_BYTES + R_BYTES + 4 * SW_BYTES);  // bias
+  if (tid < 64) Bl[tid] = bias[tid];  // visible after the first unit's barrier
 
   // weights of channels wn*32 + r, all 9 taps x 64 input channels, in registers
   frag wreg[9][4];
@@ -1158,8 +1166,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   }
   // epilogue item k of a sub-tile: pixel e_px + 16k (0..31), channels wn*32 + e_c8*8 .. +7
   const int e_c8 = lane & 3, e_px = lane >> 2;
-  const float4 b_lo = *reinterpret_cast<const float4*>(bias + wn * 32 + e_c8 * 8);
-  const float4 b_hi = *reinterpret_cast<const float4*>(bias + wn * 32 + e_c8 * 8 + 4);
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -1223,7 +1229,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(wreg[tap][kk]));  // a use: forces the wait here
-  asm volatile("" ::"v"(b_lo.x), "v"(b_hi.x));
   if (u < n_units) issue_unit(u, 0);
 #ifdef HIPAC_HALO_STAMPS
   unsigned long long c_sum[5] = {0, 0, 0, 0, 0};
@@ -1247,19 +1252,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
       const int y = ty * 8 + 4 * i + (px >> 3), x = tx * 8 + (px & 7);
       return (((size_t)tb * H + y) * W + x) * C + wn * 32 + e_c8 * 8;
     };
-    frag rv[2][RESID ? 2 : 1];
-    auto load_resid = [&](auto SUB) {
-      constexpr int i = decltype(SUB)::value;
-      if constexpr (RESID) {
-        // unconditional loads (no select, no branch): a conditional one makes the compiler drain
-        // vmcnt -- and with it the next unit's DMA -- right here instead of at the first use
+    // residual of this unit by LDS-DMA: piece j = (sub-tile j/2, item j%2) -- every lane fetches exactly
+    // the 16 bytes it adds in the epilogue (item-linear destination, no cross-lane dependency).
+    // Issued ahead of the next unit's halos: vmcnt retires in issue order.
+    if constexpr (RESID) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const frag*>(resid + item_off(i, k));
-      }
-    };
-    load_resid(std::integral_constant<int, 0>{});  // ahead of the DMA below: vmcnt retires in issue order
-    load_resid(std::integral_constant<int, 1>{});
-    if (u + (int)gridDim.x < n_units) issue_unit(u + gridDim.x, buf ^ 1);  // lands behind this whole unit
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(resid + item_off(j >> 1, j & 1)), (lptr_t)(Rl + j * 1024), 16, 0, 0);
+    }
+    const bool more = u + (int)gridDim.x < n_units;
+    if (more) issue_unit(u + gridDim.x, buf ^ 1);  // lands behind this whole unit
 
     // keep the 18 tap address bases from being hoisted out of the unit loop (they would
     // cost 18 VGPRs next to 144 of weights): make their inputs opaque per iteration
@@ -1271,56 +1273,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap - kh * 3;
-      int abase[2];
+    // 36 k16 steps (tap-major); the two activation fragments of step s + PF are requested before the
+    // MFMAs of step s, so an LDS read has PF MFMA pairs (PF x 64 cycles) to return
+    constexpr int PF = HIPAC_C64_PF;
+    frag ring[PF + 1][2];
+    auto rd_step = [&](auto S) {
+      constexpr int st = decltype(S)::value;
+      constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int hy = 4 * i + ly0 + kh, hx = lx + kw;
         const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
-        abase[i] = ((hy * HALO + hx) << 7) | ((sw ^ h) << 4);  // chunk (2kk+h) ^ sw = (2kk) ^ (h ^ sw)
+        const int abase = ((hy * HALO + hx) << 7) | ((sw ^ h) << 4);  // chunk (2kk+h) ^ sw = (2kk) ^ (h ^ sw)
+        ring[st % (PF + 1)][i] = *reinterpret_cast<const frag*>(Hl + (abase ^ (kk << 5)));
       }
+    };
+    static_for<PF>([&](auto S) { rd_step(S); });
+    static_for<36>([&](auto S) {
+      constexpr int st = decltype(S)::value;
+      if constexpr (st + PF < 36) rd_step(std::integral_constant<int, st + PF>{});
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const frag af = *reinterpret_cast<const frag*>(Hl + (abase[i] ^ (kk << 5)));
-          acc[i] = E::mfma(wreg[tap][kk], af, acc[i]);
-        }
-      }
-    }
+      for (int i = 0; i < 2; ++i) acc[i] = E::mfma(wreg[st / 4][st % 4], ring[st % (PF + 1)][i], acc[i]);
+      __builtin_amdgcn_sched_barrier(0);  // pin the read-ahead: the scheduler otherwise folds it back to one step
+    });
     __builtin_amdgcn_s_setprio(0);
     HALO_STAMP(c_t2);
 
-    // epilogue, per wave: sub-tile i -> private fp32 rows -> + bias (+ residual) ReLU -> T
-    static_for<2>([&](auto SUB) {
-      constexpr int i = decltype(SUB)::value;
+    // epilogue, per wave: SPX pixels of sub-tile i -> private fp32 rows -> + bias (+ residual) ReLU -> T
+    if constexpr (RESID) {
+      // this lane's residual pieces have landed once only the next unit's halo DMAs (issued later:
+      // 7 per wave for waves 0-1, 6 for waves 2-3) are still outstanding
+      if (!more) wait_vmcnt<0>();
+      else if (wave < 2) wait_vmcnt<7>();
+      else wait_vmcnt<6>();
+    }
+    static_for<2 * (32 / SPX)>([&](auto PH) {
+      constexpr int i = decltype(PH)::value / (32 / SPX), hf = decltype(PH)::value % (32 / SPX);
+      if (SPX == 32 || (r >> 4) == hf) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-        v[0] = acc[i][4 * q + 0];
-        v[1] = acc[i][4 * q + 1];
-        v[2] = acc[i][4 * q + 2];
-        v[3] = acc[i][4 * q + 3];
-        *reinterpret_cast<f32x4*>(Sl + r * SROW + (8 * q + 4 * h) * 4) = v;
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v[0] = acc[i][4 * q + 0];
+          v[1] = acc[i][4 * q + 1];
+          v[2] = acc[i][4 * q + 2];
+          v[3] = acc[i][4 * q + 3];
+          *reinterpret_cast<f32x4*>(Sl + (r & (SPX - 1)) * SROW + (8 * q + 4 * h) * 4) = v;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave's LDS operations complete in order
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int px = e_px + 16 * k;
+      for (int k = 0; k < SPX / 16; ++k) {
+        const int px = e_px + 16 * k;            // pixel inside the staged rows
+        constexpr int kk = SPX == 32 ? 0 : hf;   // item index inside the sub-tile = k (SPX 32) or hf (SPX 16)
+        const int ki = SPX == 32 ? k : kk;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32 + 16);
-        float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
-                      hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(Bl + wn * 32 + e_c8 * 8);
+        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(Bl + wn * 32 + e_c8 * 8 + 4);
+        float v[8] = {lo[0] + b_lo[0], lo[1] + b_lo[1], lo[2] + b_lo[2], lo[3] + b_lo[3],
+                      hi[0] + b_hi[0], hi[1] + b_hi[1], hi[2] + b_hi[2], hi[3] + b_hi[3]};
         if constexpr (RESID) {
+          const frag rvv = *reinterpret_cast<const frag*>(Rl + (2 * i + ki) * 1024 + lane * 16);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][k][e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)rvv[e];
         }
         frag ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ov[e] = (T)fmaxf(v[e], 0.f);
-        if (tile_ok) *reinterpret_cast<frag*>(out + item_off(i, k)) = ov;
+        if (tile_ok) *reinterpret_cast<frag*>(out + item_off(i, ki)) = ov;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads returned before it is overwritten
     });
