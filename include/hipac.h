@@ -228,6 +228,43 @@ int hipac_window_labels(const uint8_t* mask, int W, int H, int64_t pitch,
 int hipac_patches_normalize(const uint8_t* patches, int n, const float* lut,
                             void* out, int out_format, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * MIL head over bags of patch features: attention / mean / max pooling
+ * of each bag followed by the two-layer classifier.
+ * Replaces MILAttentionPooling.forward and MILClassifier.forward,
+ * src/models/mil_classifier.py:12-18 and :38-45, for MANY bags per call (the
+ * reference scores one bag per forward).  All pointers are DEVICE pointers; weight
+ * matrices are in the PyTorch Linear layout [out][in], float32.
+ * ------------------------------------------------------------------------- */
+#define HIPAC_MIL_ATTENTION 0
+#define HIPAC_MIL_MEAN 1
+#define HIPAC_MIL_MAX 2
+
+typedef struct {
+  const float* attn_V_w; /* [attn_dim][feature_dim]   aggregator.attn_V.weight (attention only) */
+  const float* attn_V_b; /* [attn_dim]                                                      */
+  const float* attn_U_w; /* [1][attn_dim]             aggregator.attn_U.weight              */
+  const float* attn_U_b; /* [1]                                                             */
+  const float* fc1_w;    /* [hidden_dim][feature_dim] classifier.0.weight                   */
+  const float* fc1_b;    /* [hidden_dim]                                                    */
+  const float* fc2_w;    /* [num_classes][hidden_dim] classifier.2.weight                   */
+  const float* fc2_b;    /* [num_classes]                                                   */
+  int32_t feature_dim;   /* multiple of 4, <= 2048 (512 for ResNet18 features)              */
+  int32_t attn_dim;      /* <= 256 (128 in the reference)                                   */
+  int32_t hidden_dim;    /* <= 256 (128 in the reference)                                   */
+  int32_t num_classes;   /* <= 16                                                           */
+} hipac_mil_params_t;
+
+/* feats [n][feature_dim] float32, rows of one bag contiguous; bag b = rows
+ * bag_offsets[b] .. bag_offsets[b+1]-1 (int32[n_bags+1], non-decreasing, every bag
+ * non-empty -- the caller checks).  Outputs: logits [n_bags][num_classes];
+ * attn [n] (attention pooling only, may be NULL) = softmax over each bag of
+ * attn_U(tanh(attn_V(x))); pooled [n_bags][feature_dim] (may be NULL).
+ * scores: scratch float[n] (attention only).  Asynchronous on `stream`. */
+int hipac_mil_forward(const hipac_mil_params_t* params, int pooling, const float* feats,
+                      const int32_t* bag_offsets, int n, int n_bags, float* logits, float* attn,
+                      float* pooled, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

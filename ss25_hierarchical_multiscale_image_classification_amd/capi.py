@@ -37,6 +37,12 @@ class ConvBN(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("conv_w", "bn_gamma", "bn_beta", "bn_mean", "bn_var")]
 
 
+class MilParams(C.Structure):  # hipac_mil_params_t
+    _fields_ = [(n, C.c_void_p) for n in ("attn_V_w", "attn_V_b", "attn_U_w", "attn_U_b", "fc1_w", "fc1_b", "fc2_w",
+                                           "fc2_b")] + [(n, C.c_int32) for n in ("feature_dim", "attn_dim",
+                                                                                 "hidden_dim", "num_classes")]
+
+
 class ResNet18Params(C.Structure):
     _fields_ = [
         ("stem", ConvBN),
@@ -87,6 +93,8 @@ SYMBOLS = {
         [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     ),
     "hipac_patches_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hipac_mil_forward": (C.c_int, [C.POINTER(MilParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -479,3 +487,60 @@ def patches_normalize(patches: torch.Tensor, out_format: str = "nchw_f32") -> to
                                                     _OUT_FMT[out_format], _stream())
     _check(rc, "hipac_patches_normalize")
     return out
+
+
+# ----------------------------------------------------------------------------
+# MIL head (hipac_mil_forward)
+# ----------------------------------------------------------------------------
+MIL_POOLING = {"attention": 0, "mean": 1, "max": 2}
+
+
+def mil_forward(sd: Dict[str, torch.Tensor], pooling: str, feats: torch.Tensor, bag_offsets: torch.Tensor,
+                want_attn: bool = True, want_pooled: bool = False):
+    """Score many bags at once.  ``sd``: MILClassifier state_dict tensors (float32, on the device of
+    ``feats``); ``feats`` float32[n,F] with the rows of a bag contiguous; ``bag_offsets`` int32[n_bags+1]
+    (CPU or device; validated on the host).  Returns (logits[n_bags,C], attn[n] or None, pooled or None)."""
+    if pooling not in MIL_POOLING:
+        raise ValueError("Unknown pooling: choose from 'attention', 'mean', 'max'")
+    _require_gpu(feats)
+    if feats.dtype != torch.float32 or feats.dim() != 2:
+        raise HipacError("feats must be float32[n, feature_dim]")
+    offs_host = bag_offsets.detach().to("cpu", torch.int64)
+    n, F = int(feats.shape[0]), int(feats.shape[1])
+    if offs_host.dim() != 1 or offs_host.numel() < 2 or int(offs_host[0]) != 0 or int(offs_host[-1]) != n or \
+            bool((offs_host[1:] <= offs_host[:-1]).any()):
+        raise HipacError("bag_offsets must start at 0, end at n and increase strictly (no empty bags)")
+    n_bags = offs_host.numel() - 1
+    dev = feats.device
+    offs = offs_host.to(torch.int32).to(dev)
+
+    def w(key):
+        t = sd[key]
+        if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+            raise HipacError(f"MIL weight {key} must be a contiguous float32 tensor on {dev}")
+        return t
+
+    p = MilParams()
+    attention = pooling == "attention"
+    if attention:
+        p.attn_V_w, p.attn_V_b = w("aggregator.attn_V.weight").data_ptr(), w("aggregator.attn_V.bias").data_ptr()
+        p.attn_U_w, p.attn_U_b = w("aggregator.attn_U.weight").data_ptr(), w("aggregator.attn_U.bias").data_ptr()
+        p.attn_dim = int(sd["aggregator.attn_V.weight"].shape[0])
+        if tuple(sd["aggregator.attn_V.weight"].shape) != (p.attn_dim, F):
+            raise HipacError("aggregator.attn_V.weight does not match feature_dim")
+    p.fc1_w, p.fc1_b = w("classifier.0.weight").data_ptr(), w("classifier.0.bias").data_ptr()
+    p.fc2_w, p.fc2_b = w("classifier.2.weight").data_ptr(), w("classifier.2.bias").data_ptr()
+    p.feature_dim, p.hidden_dim = F, int(sd["classifier.0.weight"].shape[0])
+    p.num_classes = int(sd["classifier.2.weight"].shape[0])
+    if tuple(sd["classifier.0.weight"].shape) != (p.hidden_dim, F):
+        raise HipacError("classifier.0.weight does not match feature_dim")
+    logits = torch.empty((n_bags, p.num_classes), dtype=torch.float32, device=dev)
+    attn = torch.empty((n,), dtype=torch.float32, device=dev) if (attention and want_attn) else None
+    pooled = torch.empty((n_bags, F), dtype=torch.float32, device=dev) if want_pooled else None
+    scores = torch.empty((n,), dtype=torch.float32, device=dev) if attention else None
+    with torch.cuda.device(dev):
+        rc = load_library().hipac_mil_forward(C.byref(p), MIL_POOLING[pooling], feats.data_ptr(), offs.data_ptr(), n,
+                                              n_bags, logits.data_ptr(), _ptr(attn), _ptr(pooled), _ptr(scores),
+                                              _stream())
+    _check(rc, "hipac_mil_forward")
+    return logits, attn, pooled

@@ -248,3 +248,18 @@ def test_fp32_parity_mode_meets_1e3_with_margin_and_labels_exactly():
     assert elem < 1e-3  # element-wise relative, not just norm-relative
     margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
     assert torch.equal(lab.cpu()[margin > 1e-5], ref_l.argmax(1)[margin > 1e-5])
+
+
+@pytest.mark.parametrize("n", [2047, 2049, 4099])
+def test_large_ragged_batches_two_lanes_default_schedule(n):
+    # default schedule (sub-batch 512, group 4096, two lanes from 2048 patches): ragged sizes around
+    # the lane / group thresholds give the same per-patch results as scoring the patches one lane at
+    # a time in small pieces
+    sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
+    net = capi.PackedResNet18(sd, precision="fp16")
+    u8 = synth.synth_patches_u8(n, seed=n, device="cuda")
+    f, l, lab = net.forward(u8, want_logits=True, want_labels=True)
+    pieces = [net.forward(u8[i:i + 700].contiguous(), want_logits=True, want_labels=True) for i in range(0, n, 700)]
+    assert torch.equal(f, torch.cat([p[0] for p in pieces]))
+    assert torch.equal(l, torch.cat([p[1] for p in pieces]))
+    assert torch.equal(lab, torch.cat([p[2] for p in pieces]))
