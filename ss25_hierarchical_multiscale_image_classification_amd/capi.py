@@ -318,6 +318,13 @@ class PackedResNet18:
     def tap(self, batch: int, tap: int) -> torch.Tensor:
         """Intermediate activation of the last forward (float32 NCHW); tests only."""
         shapes = [(64, 112), (64, 56), (64, 56), (64, 56), (128, 28), (128, 28), (256, 14), (256, 14), (512, 7), (512, 7)]
+        if not 0 <= tap < len(shapes):
+            raise HipacError(f"tap index {tap} out of range")
+        # the C entry point trusts `batch` (it addresses the workspace with that batch's plan): never let it
+        # exceed what the workspace of the last forward was sized for
+        if self._ws is None or batch < 1 or \
+                self._lib.hipac_resnet18_workspace_bytes(batch, self._lib.hipac_weights_precision(self.handle)) > self._ws.numel():
+            raise HipacError(f"tap: batch {batch} does not fit the workspace of the last forward")
         c, h = shapes[tap]
         dst = torch.empty((batch, c, h, h), dtype=torch.float32, device=self._ws.device)
         with torch.cuda.device(dst.device):

@@ -876,6 +876,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 // applied while the patch is staged (a 3 x 256 table of T values in LDS == the fp32 LUT
 // rounded to T, i.e. exactly what hipac_patches_normalize would have written), so the padded
 // NHWC4 tensor (427 KB per patch written and read back) never exists.
+#ifndef HIPAC_STEM_TILE16
+#define HIPAC_STEM_TILE16 0  // measured: 660 vs 605 ns per patch (+12 % MFMA work outweighs conflict-free reads)
+#endif
+constexpr int kStemTilesPerImage = HIPAC_STEM_TILE16 ? 64 : 56;
+
 template <typename T, bool U8IN>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin_, const T* __restrict__ wgt,
                                                         const float* __restrict__ bias, T* __restrict__ out,
@@ -884,16 +889,26 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
   const T* xin = reinterpret_cast<const T*>(xin_);
   using E = Elem<T>;
   using frag = typename E::frag;
+#if HIPAC_STEM_TILE16
+  // 16 x 16 stem pixels in eight 8 x 4 lane blocks over a 320-byte patch pitch: every ds_read_b128 lane
+  // group of the MFMA loop covers all 16 bank groups (conflict-free); the 7 x 7 pooled tile uses 15 x 15
+  // of them (12 % more MFMA work than the 17 x 15 tile, whose 15-pixel rows cannot avoid 2-way conflicts)
+  constexpr int PTH = 7, PTW = 7;                                       // pooled tile
+  constexpr int STW = 16, STH = 16, NPX = STW * STH;                    // 256 stem pixels
+  constexpr int PROWS = 2 * STH + 5, PCOLS = 40;                        // 37 x 40 input pixels (8 B each)
+#else
   constexpr int PTH = 8, PTW = 7;                                       // pooled tile
   constexpr int STW = 2 * PTW + 1, STH = 2 * PTH + 1, NPX = STW * STH;  // 15 x 17 = 255 stem pixels
   constexpr int PROWS = 2 * STH + 5, PCOLS = 36;                        // 39 x 36 input pixels (8 B each)
+#endif
+  static_assert(56 / PTW * (56 / PTH) == kStemTilesPerImage, "tile count");
   constexpr int PPR = PCOLS / 2;                                        // 16-byte pieces per patch row
   constexpr int NPIECE = PROWS * PPR;                                   // 702
   constexpr int PF = (NPIECE + 255) / 256;                              // pieces per thread (3)
   constexpr int TILES_X = 56 / PTW, TILES_Y = 56 / PTH, TPI = TILES_X * TILES_Y;  // 8 x 7 = 56 per image
   constexpr int SPX = 144;  // stem-tile pixel stride in LDS: 128 B of channels + 16 B pad (bank spread)
   constexpr int P_BYTES = PROWS * PCOLS * 8, S_BYTES = 256 * SPX;
-  constexpr int RAWROW = 112, RAWDW = RAWROW / 4;                       // raw uint8 window per patch row
+  constexpr int RAWROW = (PCOLS * 3 + 3 + 3) / 4 * 4, RAWDW = RAWROW / 4;  // raw uint8 window per patch row
   constexpr int RAW_BYTES = U8IN ? PROWS * RAWROW + 3 * 256 * 2 : 0;    // + the T-typed normalise table
   constexpr int NRAW = PROWS * RAWDW, PFR = (NRAW + 255) / 256;          // 1092 dwords, 5 per thread
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + S_BYTES + RAW_BYTES];
@@ -926,13 +941,22 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(bias + j * 32 + 8 * q + 4 * h);
 
   // the two stem pixels of this lane (sub-tiles 2*wave, 2*wave+1); pixel 255 does not exist
-  int P[2], a_rd[2], ly[2], lx[2];
+  int P[2], a_rd[2], ly[2], lx[2], sidx[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     P[i] = (2 * wave + i) * 32 + r;
+#if HIPAC_STEM_TILE16
+    const int sub = 2 * wave + i;                   // block (sub & 1, sub >> 1) of 8 x 4 pixels
+    lx[i] = (sub & 1) * 8 + (r & 7);
+    ly[i] = (sub >> 1) * 4 + (r >> 3);
+#else
     const int Pc = P[i] < NPX ? P[i] : NPX - 1;
     ly[i] = Pc / STW;
     lx[i] = Pc - ly[i] * STW;
+#endif
+    // row-major index in the LDS stem tile; lane 255 of the 17 x 15 tile (a pixel that does not exist)
+    // keeps its own dummy row 255 -- it must not share a row with pixel 254
+    sidx[i] = P[i] < NPX ? ly[i] * STW + lx[i] : P[i];
     a_rd[i] = ((2 * ly[i]) * PCOLS + 2 * lx[i]) * 8 + 16 * h;
   }
 
@@ -970,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
         const int i = tid + 256 * k;
         const int row = i / PPR, cp = i - row * PPR;
         const int R = R0 + row, C = C0 + 2 * cp;
-        const bool ok = i < NPIECE && R >= 0 && C >= 0;
+        const bool ok = i < NPIECE && R >= 0 && C >= 0 && R < kPadH && C + 1 < kPadW;
         const u32x4 v = *reinterpret_cast<const u32x4*>(img + (ok ? ((size_t)R * kPadW + C) * 8 : 0));
         pre[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
       });
@@ -1076,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
           ov[1] = (T)(inside ? fmaxf(acc[i][j][4 * q + 1] + bv[j][q].y, 0.f) : 0.f);
           ov[2] = (T)(inside ? fmaxf(acc[i][j][4 * q + 2] + bv[j][q].z, 0.f) : 0.f);
           ov[3] = (T)(inside ? fmaxf(acc[i][j][4 * q + 3] + bv[j][q].w, 0.f) : 0.f);
-          *reinterpret_cast<typename E::vec4*>(Sl + P[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = ov;
+          *reinterpret_cast<typename E::vec4*>(Sl + sidx[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = ov;
         }
     }
     __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]
@@ -1364,6 +1388,181 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// layer2 entry kernel: 3x3 / stride 2 / 64 -> 128 channels, 56x56 -> 28x28 (+BN+ReLU) AND the
+// block's 1x1 / stride 2 projection shortcut (+BN), one launch, one pass over the input.
+// Same skeleton as the layer1 kernel: persistent workgroups, every lane keeps ITS weight
+// fragments in registers (wave w = output channels 32w .. 32w+31: 36 fragments of the 3x3 conv
+// + 4 of the projection = 160 VGPRs), LDS serves only activation fragments, halos double-buffered
+// across units by LDS-DMA, one workgroup barrier per unit, per-wave barrier-free epilogues.
+//   * unit = one tile of 7 x 4 output pixels (28 of the 32 MFMA columns; 28 tiles per image);
+//     all four waves read the same activation fragments (different weights)
+//   * its 15 x 9 input halo is stored as [row hy][p] with the EVEN columns first
+//     (p = (hx & 1) * 8 + hx / 2, 16 slots per row): a tap (kh, kw) then reads consecutive
+//     slots p = (kw & 1) * 8 + x + kw / 2 for consecutive output x -- the stride disappears.
+//     16-byte chunk c of slot (hy, p) sits at c ^ (((p >> 1) & 1) | (((hy >> 1) & 3) << 1)):
+//     every ds_read_b128 lane group covers all 16 bank groups (simulated: 4.0 LDS cycles per read)
+//   * the projection reads exactly the centre tap's fragments: 4 extra MFMAs, no extra LDS reads
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_c64_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                               const float* __restrict__ bias,
+                                                               const T* __restrict__ wgt_p,
+                                                               const float* __restrict__ bias_p, T* __restrict__ out,
+                                                               T* __restrict__ out_p, int n_tiles,
+                                                               const char* __restrict__ zero_page) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int HI = 56, WI = 56, C = 64, HO = 28, WO = 28, CO = 128;
+  constexpr int TW = 7, TH = 4, TPI = (WO / TW) * (HO / TH);  // 4 x 7 = 28 tiles per image
+  constexpr int HPIECES = 18;                                // 9 rows x 16 slots = 144 slots
+  constexpr int H_BYTES = HPIECES * 1024;
+  constexpr int SROW = 144;                                  // staging row: 32 fp32 + 16 B pad
+  constexpr int SW_BYTES = 32 * SROW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * H_BYTES + 4 * SW_BYTES + 2 * CO * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* const Sl = smem + 2 * H_BYTES + wave * SW_BYTES;
+  float* const Bl = reinterpret_cast<float*>(smem + 2 * H_BYTES + 4 * SW_BYTES);  // bias[128], bias_p[128]
+  if (tid < CO) {
+    Bl[tid] = bias[tid];
+    Bl[CO + tid] = bias_p[tid];
+  }
+
+  // weights of output channel 32*wave + r: 9 taps x 64 input channels, and the projection's 64
+  frag wreg[9][4], wpr[4];
+  {
+    const char* wb = reinterpret_cast<const char*>(wgt) + (size_t)(wave * 32 + r) * (9 * C * 2) + 16 * h;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wreg[tap][kk] = *reinterpret_cast<const frag*>(wb + tap * 128 + kk * 32);
+    const char* pb = reinterpret_cast<const char*>(wgt_p) + (size_t)(wave * 32 + r) * (C * 2) + 16 * h;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wpr[kk] = *reinterpret_cast<const frag*>(pb + kk * 32);
+  }
+  const int e_c8 = lane & 3, e_px = lane >> 2;  // epilogue item k: pixel e_px + 16k, channels 32*wave + 8*e_c8 ..
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const int prow = lane >> 3, dchunk = lane & 7;
+  const char* in_b = reinterpret_cast<const char*>(in);
+
+  // halo DMA: tile-independent part of every piece computed once (byte offset from the tile's first
+  // input pixel, edge bits in the low nibble: bit 0 = halo row 0, bit 1 = halo column 0).
+  constexpr int NPW = (HPIECES + 3) / 4;  // pieces per wave (5; waves 2, 3 have 4)
+  int piece_pk[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int q = (wave + 4 * k) * 8 + prow;  // slot = hy*16 + p
+    const int hy = (q >> 4) < 9 ? (q >> 4) : 8;
+    int pcol = q & 15;
+    pcol = pcol < 15 ? pcol : 14;             // slot 15 of a row does not exist: re-fetch slot 14 (never read)
+    const int hx = pcol < 8 ? 2 * pcol : 2 * (pcol - 8) + 1;
+    const int key = ((pcol >> 1) & 1) | (((hy >> 1) & 3) << 1);
+    const int rel = ((hy - 1) * WI + (hx - 1)) * (C * 2) + (dchunk ^ key) * 16;
+    piece_pk[k] = rel | (hy == 0 ? 1 : 0) | (hx == 0 ? 2 : 0);
+  }
+  auto issue_unit = [&](int tile, int buf) {
+    const int b = tile / TPI, t = tile - b * TPI;
+    const int ty = t / (WO / TW), tx = t - ty * (WO / TW);
+    const char* tbase = in_b + (((size_t)b * HI + ty * (2 * TH)) * WI + tx * (2 * TW)) * (C * 2);
+    const int tmask = (ty == 0 ? 1 : 0) | (tx == 0 ? 2 : 0);
+    static_for<NPW>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const int pc = wave + 4 * k;
+      if (pc < HPIECES) {
+        const bool ok = (piece_pk[k] & tmask) == 0;
+        const char* src = ok ? tbase + (piece_pk[k] & ~15) : zero_page + dchunk * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * H_BYTES + pc * 1024), 16, 0, 0);
+      }
+    });
+  };
+
+  // this lane's output pixel inside the tile: (y, x) = (r / 8, r % 8); column 7 does not exist and
+  // re-reads column 6 (same address: an LDS broadcast), its results are never stored
+  int lx = (r & 7) < TW ? (r & 7) : TW - 1, ly = r >> 3;
+
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(wreg[tap][kk]));  // weight loads retire before the loop
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(wpr[kk]));
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) issue_unit(tile, 0);
+  for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // this tile's halo landed; every wave is past its reads of the other buffer
+    if (tile + (int)gridDim.x < n_tiles) issue_unit(tile + gridDim.x, buf ^ 1);  // lands behind this whole unit
+
+    const int tb = tile / TPI, tt = tile - tb * TPI;
+    const int ty = tt / (WO / TW), tx = tt - ty * (WO / TW);
+    asm volatile("" : "+v"(lx), "+v"(ly));  // keep the tap address bases from being hoisted (VGPRs)
+    const unsigned char* const Hl = smem + buf * H_BYTES;
+    f32x16 acc, accp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = accp[e] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int PF = 2;
+    frag ring[PF + 1];
+    auto rd_step = [&](auto S) {
+      constexpr int st = decltype(S)::value;
+      constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
+      const int hy = 2 * ly + kh, pcol = (kw & 1) * 8 + lx + (kw >> 1);
+      const int key = ((pcol >> 1) & 1) | (((hy >> 1) & 3) << 1);
+      ring[st % (PF + 1)] = *reinterpret_cast<const frag*>(Hl + (((hy << 4) + pcol) << 7) + (((2 * kk + h) ^ key) << 4));
+    };
+    static_for<PF>([&](auto S) { rd_step(S); });
+    static_for<36>([&](auto S) {
+      constexpr int st = decltype(S)::value;
+      if constexpr (st + PF < 36) rd_step(std::integral_constant<int, st + PF>{});
+      acc = E::mfma(wreg[st / 4][st % 4], ring[st % (PF + 1)], acc);
+      if constexpr (st / 4 == 4) accp = E::mfma(wpr[st % 4], ring[st % (PF + 1)], accp);  // centre tap = 1x1/2 input
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __builtin_amdgcn_s_setprio(0);
+
+    // epilogue, per wave: [32 px][32 ch] fp32 through private staging rows -> 16-byte items
+    auto flush = [&](const f32x16& a, const float* bl, bool relu, T* dst) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = a[4 * q + 0];
+        v[1] = a[4 * q + 1];
+        v[2] = a[4 * q + 2];
+        v[3] = a[4 * q + 3];
+        *reinterpret_cast<f32x4*>(Sl + r * SROW + (8 * q + 4 * h) * 4) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave's LDS operations complete in order
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int px = e_px + 16 * k;
+        const int y = px >> 3, x = px & 7;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32 + 16);
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bl + wave * 32 + e_c8 * 8);
+        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bl + wave * 32 + e_c8 * 8 + 4);
+        float v[8] = {lo[0] + b_lo[0], lo[1] + b_lo[1], lo[2] + b_lo[2], lo[3] + b_lo[3],
+                      hi[0] + b_hi[0], hi[1] + b_hi[1], hi[2] + b_hi[2], hi[3] + b_hi[3]};
+        frag ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (T)(relu ? fmaxf(v[e], 0.f) : v[e]);
+        if (x < TW)
+          *reinterpret_cast<frag*>(dst + ((((size_t)tb * HO + ty * TH + y) * WO + tx * TW + x) * CO + wave * 32 +
+                                         e_c8 * 8)) = ov;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads returned before it is overwritten
+    };
+    flush(acc, Bl, true, out);
+    flush(accp, Bl + CO, false, out_p);
+  }
+}
+
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
 // post-ReLU (>= 0) so the implicit -inf padding never wins; out-of-range taps
 // are simply skipped.
@@ -1493,6 +1692,9 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
   return (int)hipGetLastError();
 }
 
+#ifndef HIPAC_USE_S2C64
+#define HIPAC_USE_S2C64 1  // layer2's 3x3/2 conv + projection on the register-weight kernel
+#endif
 #ifndef HIPAC_FUSE_PROJ
 #define HIPAC_FUSE_PROJ 1
 #endif
@@ -1502,6 +1704,13 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
 template <typename T, int CIN, int COUT, int HI>
 static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* out, void* out_p, int n, hipStream_t s,
                        const char* zero_page) {
+  if constexpr (HIPAC_USE_S2C64 && CIN == 64 && COUT == 128 && HI == 56) {
+    const int n_tiles = n * 28;
+    const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent, 2 workgroups per CU
+    hipLaunchKernelGGL((conv3x3s2_c64_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias,
+                       (const T*)wp.w, wp.bias, (T*)out, (T*)out_p, n_tiles, zero_page);
+    return (int)hipGetLastError();
+  }
   using C = TileCfg<COUT>;
   constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
   constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
@@ -1586,7 +1795,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     if (p.fuse_stem) {
     // op 0 = fused stem + max-pool (the 112x112 stem map is never materialised), op 1 = nothing
     if (ops.take()) {
-      const int n_tiles = ne * 56;
+      const int n_tiles = ne * kStemTilesPerImage;
       const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent: 2 workgroups per CU
       if (p.u8_input)
         hipLaunchKernelGGL((stem_pool_kernel<T, true>), dim3(grid), dim3(256), 0, s, xin, (const T*)net.stem.w,
