@@ -433,9 +433,15 @@ class LevelPlanes:
                        "hipac_level_window_stats")
         return sums, keep
 
-    def gather(self, xy: torch.Tensor) -> torch.Tensor:
+    def gather(self, xy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8[n,224,224,3] resized pixels of the windows at ``xy``; ``out``: write into this
+        (contiguous, e.g. a slice of a larger batch buffer) instead of allocating."""
         n = xy.shape[0]
-        out = torch.empty((n, PATCH, PATCH, 3), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((n, PATCH, PATCH, 3), dtype=torch.uint8, device=self.device)
+        elif out.dtype != torch.uint8 or tuple(out.shape) != (n, PATCH, PATCH, 3) or not out.is_contiguous() or \
+                out.device != self.device:
+            raise HipacError("gather: out must be a contiguous uint8[n,224,224,3] tensor on the planes' device")
         if n:
             with torch.cuda.device(self.device):
                 _check(self._lib.hipac_level_gather(self.dimg.data_ptr(), self.W, self.H, self.P, xy.data_ptr(), n,

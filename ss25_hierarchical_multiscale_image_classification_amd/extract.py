@@ -225,11 +225,14 @@ class LevelWindows:
     def kept_index(self) -> torch.Tensor:
         return torch.nonzero(self.keep, as_tuple=False).flatten()
 
-    def patches(self, idx: torch.Tensor) -> torch.Tensor:
-        """uint8[len(idx),224,224,3] resized pixels of the selected windows."""
+    def patches(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8[len(idx),224,224,3] resized pixels of the selected windows (into ``out`` if given)."""
         if self._all_u8 is not None:
-            return self._all_u8.index_select(0, idx)
-        return self.planes.gather(self.xy.index_select(0, idx))
+            if out is None:
+                return self._all_u8.index_select(0, idx)
+            torch.index_select(self._all_u8, 0, idx, out=out)
+            return out
+        return self.planes.gather(self.xy.index_select(0, idx), out=out)
 
     def meta(self, idx: torch.Tensor) -> torch.Tensor:
         xy = self.xy.index_select(0, idx)
@@ -267,37 +270,55 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     Returns device tensors (feats[n,512], logits[n,C] or None, pred int64[n] or None,
     meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order."""
     has_fc = net.num_classes > 0 and want_logits
-    xs, metas = [], []
-    for x, meta in WSIPatchStream(slide, levels, batch_windows, net.precision, stride):
-        if x.shape[0]:
-            xs.append(x)
-            metas.append(meta)
     dev = slide.device
-    if not xs:
+    # pass 1: every extractor decision of every level (whole-level kernels; one host sync per level
+    # for the kept count)
+    lws, kepts = [], []
+    for level in levels:
+        st = stride(level) if callable(stride) else stride
+        lw = LevelWindows(slide, level, st)
+        lws.append(lw)
+        kepts.append(lw.kept_index())
+    n_total = sum(int(k.shape[0]) for k in kepts)
+    if n_total == 0:
         return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
-    feats, logits, preds = [], [], []
-    pend, pend_n = [], 0
-
-    def flush():
-        nonlocal pend, pend_n
-        if not pend:
-            return
-        xb = torch.cat(pend) if len(pend) > 1 else pend[0]
-        f, l, p = net.forward(xb, want_feats=True, want_logits=has_fc, want_labels=has_fc)
-        feats.append(f)
+    metas = torch.cat([lw.meta(k) for lw, k in zip(lws, kepts) if k.shape[0]])
+    # pass 2: ONE uint8 batch buffer for the whole slide; the resize/gather of the windows runs on a
+    # side stream in pieces of `batch_windows`, the ResNet follows it on the caller's stream in batches of
+    # FWD patches (zero-copy slices; the late layers need thousands of patches per launch)
+    FWD = 8192
+    buf = torch.empty((n_total, 224, 224, 3), dtype=torch.uint8, device=dev)
+    feats = torch.empty((n_total, 512), dtype=torch.float32, device=dev)
+    logits = torch.empty((n_total, net.num_classes), dtype=torch.float32, device=dev) if has_fc else None
+    preds = torch.empty((n_total,), dtype=torch.int64, device=dev) if has_fc else None
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(main)
+    marks = []  # (patches gathered so far, event)
+    done = 0
+    with torch.cuda.stream(side):
+        for lw, kept in zip(lws, kepts):
+            for i0 in range(0, kept.shape[0], batch_windows):
+                idx = kept[i0:i0 + batch_windows]
+                lw.patches(idx, out=buf[done:done + idx.shape[0]])
+                done += idx.shape[0]
+                ev = torch.cuda.Event()
+                ev.record(side)
+                marks.append((done, ev))
+    buf.record_stream(side)
+    scored, mi = 0, 0
+    while scored < n_total:
+        end = min(n_total, scored + FWD)
+        while marks[mi][0] < end:
+            mi += 1
+        main.wait_event(marks[mi][1])
+        f, l, p = net.forward(buf[scored:end], want_feats=True, want_logits=has_fc, want_labels=has_fc)
+        feats[scored:end] = f
         if has_fc:
-            logits.append(l)
-            preds.append(p)
-        pend, pend_n = [], 0
-
-    for x in xs:
-        pend.append(x)
-        pend_n += x.shape[0]
-        if pend_n >= 8192:
-            flush()
-    flush()
-    return (torch.cat(feats), torch.cat(logits) if has_fc else None, torch.cat(preds) if has_fc else None,
-            torch.cat(metas))
+            logits[scored:end] = l
+            preds[scored:end] = p
+        scored = end
+    return feats, logits, preds, metas
 
 
 def save_patch_pngs(slide: DeviceSlide, level: int, out_dir: str, stride: Optional[int] = None) -> int:
