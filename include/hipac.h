@@ -265,6 +265,17 @@ int hipac_mil_forward(const hipac_mil_params_t* params, int pooling, const float
                       const int32_t* bag_offsets, int n, int n_bags, float* logits, float* attn,
                       float* pooled, float* scores, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * NT-Xent loss of the SimCLR step, value and gradient in one call (SURVEY a-12).
+ * Replaces nt_xent_loss, src/models/simclr.py:31-54, and its autograd backward:
+ * z = cat(z_i, z_j) float32 [2n][d] (device), loss float32[1] (device),
+ * dz float32 [2n][d] = d loss / d z (NULL: value only).  d <= 256.
+ * scratch: hipac_ntxent_scratch_bytes(n, d) bytes of device memory.
+ * ------------------------------------------------------------------------- */
+size_t hipac_ntxent_scratch_bytes(int n, int d);
+int hipac_ntxent_fwd_bwd(const float* z, int n, int d, float temperature, float* loss, float* dz,
+                         void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = CSRC / os.environ.get("HIPAC_OBJ_DIR", "build")
 LIB = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")
-SOURCES = ["hipac_capi.hip", "preprocess.hip", "level_planes.hip", "mil.hip", "conv_bf16.hip", "conv_f16.hip",
+SOURCES = ["hipac_capi.hip", "preprocess.hip", "level_planes.hip", "mil.hip", "ntxent.hip", "conv_bf16.hip", "conv_f16.hip",
            "conv_f32.hip"]
 HEADERS = ["common.h", "conv_igemm.h", "../../include/hipac.h"]
 ARCH = "gfx950"

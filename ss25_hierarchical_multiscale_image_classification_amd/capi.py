@@ -93,6 +93,9 @@ SYMBOLS = {
         [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     ),
     "hipac_patches_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hipac_ntxent_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hipac_ntxent_fwd_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
     "hipac_mil_forward": (C.c_int, [C.POINTER(MilParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -557,3 +560,24 @@ def mil_forward(sd: Dict[str, torch.Tensor], pooling: str, feats: torch.Tensor, 
                                               _stream())
     _check(rc, "hipac_mil_forward")
     return logits, attn, pooled
+
+
+# ----------------------------------------------------------------------------
+# NT-Xent (hipac_ntxent_fwd_bwd)
+# ----------------------------------------------------------------------------
+def ntxent_fwd_bwd(z: torch.Tensor, temperature: float, want_grad: bool = True):
+    """z = cat(z_i, z_j) float32[2n,d] on cuda -> (loss float32[] , dz float32[2n,d] or None)."""
+    _require_gpu(z)
+    if z.dtype != torch.float32 or z.dim() != 2 or z.shape[0] % 2 or z.shape[0] == 0:
+        raise HipacError("ntxent: z must be float32[2n, d]")
+    n, d = z.shape[0] // 2, z.shape[1]
+    lib = load_library()
+    nbytes = lib.hipac_ntxent_scratch_bytes(n, d)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    with torch.cuda.device(z.device):
+        rc = lib.hipac_ntxent_fwd_bwd(z.data_ptr(), n, d, float(temperature), loss.data_ptr(), _ptr(dz),
+                                      scratch.data_ptr(), nbytes, _stream())
+    _check(rc, "hipac_ntxent_fwd_bwd")
+    return loss, dz

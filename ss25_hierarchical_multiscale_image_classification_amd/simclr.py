@@ -39,12 +39,36 @@ class SimCLRModel(_HipBacked):
         return self.projector(feats)
 
 
+class _NTXentHip(torch.autograd.Function):
+    """Value and gradient from one native call (hipac_ntxent_fwd_bwd); the gradient is kept for backward."""
+
+    @staticmethod
+    def forward(ctx, z, temperature):
+        from . import capi
+
+        loss, dz = capi.ntxent_fwd_bwd(z.contiguous(), temperature, want_grad=z.requires_grad)
+        ctx.save_for_backward(dz) if dz is not None else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dz,) = ctx.saved_tensors
+        return dz * grad_out, None
+
+
 def nt_xent_loss(z_i: torch.Tensor, z_j: torch.Tensor, temperature: float = 0.5,
-                 gather: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> torch.Tensor:
+                 gather: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 backend: Optional[str] = None) -> torch.Tensor:
     """src/models/simclr.py:31-54.  ``gather`` (optional) maps the local [n,D] block to
-    the global [N,D] one, differentiably, before the loss."""
+    the global [N,D] one, differentiably, before the loss.  ``backend``: "hip" (the native
+    kernel; default for float32 ROCm tensors with D <= 256), "torch" (the reference's own
+    formula on any device)."""
     if gather is not None:
         z_i, z_j = gather(z_i), gather(z_j)
+    if backend is None:
+        backend = "hip" if (z_i.is_cuda and z_i.dtype == torch.float32 and z_i.shape[1] <= 256) else "torch"
+    if backend == "hip":
+        return _NTXentHip.apply(torch.cat([z_i, z_j], dim=0), float(temperature))
     n = z_i.size(0)
     z = F.normalize(torch.cat([z_i, z_j], dim=0), dim=1)
     sim = torch.matmul(z, z.T) / temperature
