@@ -468,13 +468,17 @@ def window_labels(mask: torch.Tensor, xy: torch.Tensor, P: int) -> torch.Tensor:
     return labels
 
 
-def mask_cells(mask: torch.Tensor) -> torch.Tensor:
-    """uint8[H,W] mask -> uint8[ceil(H/224), ceil(W/224)] "any pixel > 0" flags."""
+def mask_cells(mask: torch.Tensor, width: Optional[int] = None) -> torch.Tensor:
+    """uint8[H,Wp] mask (true width ``width`` <= Wp, default Wp; a row pitch that is a multiple of 16
+    takes the 16-byte-load path) -> uint8[ceil(H/224), ceil(width/224)] "any pixel > 0" flags."""
     _require_gpu(mask)
-    H, W = mask.shape
+    H, Wp = mask.shape
+    W = Wp if width is None else int(width)
+    if not 0 < W <= Wp:
+        raise HipacError("mask_cells: width out of range")
     out = torch.empty(((H + 223) // 224, (W + 223) // 224), dtype=torch.uint8, device=mask.device)
     with torch.cuda.device(mask.device):
-        _check(load_library().hipac_mask_cells(mask.data_ptr(), W, H, W, out.data_ptr(), _stream()), "hipac_mask_cells")
+        _check(load_library().hipac_mask_cells(mask.data_ptr(), W, H, Wp, out.data_ptr(), _stream()), "hipac_mask_cells")
     return out
 
 

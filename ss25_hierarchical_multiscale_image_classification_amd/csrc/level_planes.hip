@@ -307,24 +307,35 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned* __restrict_
   }
 }
 
-// mask -> per-cell "any pixel > 0" flags (cells of 224 x 224, zero outside the mask).
-// block = one cell row of 16 mask rows x 4 cells... simple form: one workgroup per cell.
+// mask -> per-cell "any pixel > 0" flags (cells of 224 x 224, zero outside the mask).  One workgroup per
+// cell: thread -> (16-byte piece of the cell's 14, row group of 18); rows are OR-ed as 16-byte vectors
+// (`vec` = pointer and pitch allow it), the piece cut by the level's right edge byte by byte.
 __global__ __launch_bounds__(256) void mask_cells_kernel(const uint8_t* __restrict__ mask, int W, int H,
-                                                         long long pitch, int ncx, unsigned char* __restrict__ cellany) {
+                                                         long long pitch, int ncx, int vec,
+                                                         unsigned char* __restrict__ cellany) {
   __shared__ int any_s;
   const int cx = blockIdx.x, cy = blockIdx.y, tid = threadIdx.x;
   if (tid == 0) any_s = 0;
   __syncthreads();
   const int x0 = cx * kLat, y0 = cy * kLat;
   const int cols = min(kLat, W - x0), rows = min(kLat, H - y0);
-  int found = 0;
-  if (cols > 0 && rows > 0) {
-    for (int i = tid; i < rows * cols && !found; i += 256) {
-      const int ry = i / cols, rx = i - ry * cols;
-      if (mask[(long long)(y0 + ry) * pitch + x0 + rx] > 0) found = 1;
+  unsigned acc = 0;
+  constexpr int PIECES = kLat / 16;  // 14
+  const int pc = tid % PIECES, rg = tid / PIECES;  // 18 row groups (252 threads)
+  if (rg < 18 && cols > 0 && rows > 0) {
+    const int c0 = pc * 16;
+    const uint8_t* base = mask + (long long)y0 * pitch + x0 + c0;
+    if (vec && c0 + 16 <= cols) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      for (int ry = rg; ry < rows; ry += 18) v |= *reinterpret_cast<const u32x4*>(base + (long long)ry * pitch);
+      acc = v[0] | v[1] | v[2] | v[3];
+    } else if (c0 < cols) {
+      const int nb = min(16, cols - c0);
+      for (int ry = rg; ry < rows; ry += 18)
+        for (int k = 0; k < nb; ++k) acc |= base[(long long)ry * pitch + k];
     }
   }
-  if (found) atomicOr(&any_s, 1);
+  if (acc) atomicOr(&any_s, 1);
   __syncthreads();
   if (tid == 0) cellany[cy * ncx + cx] = (unsigned char)any_s;
 }
@@ -453,8 +464,9 @@ extern "C" {
 int hipac_mask_cells(const uint8_t* mask, int W, int H, int64_t pitch, uint8_t* cellany, void* stream) {
   HIPAC_REQUIRE(mask && cellany && W > 0 && H > 0 && pitch >= W, HIPAC_EINVAL, "mask_cells: bad argument");
   const int ncx = (W + kLat - 1) / kLat, ncy = (H + kLat - 1) / kLat;
+  const int vec = (((uintptr_t)mask | (uintptr_t)pitch) & 15) == 0;
   hipLaunchKernelGGL(mask_cells_kernel, dim3(ncx, ncy), dim3(256), 0, (hipStream_t)stream, mask, W, H,
-                     (long long)pitch, ncx, cellany);
+                     (long long)pitch, ncx, vec, cellany);
   HIPAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

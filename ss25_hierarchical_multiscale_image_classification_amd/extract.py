@@ -120,7 +120,11 @@ class DeviceSlide:
             return None
         if level not in self._masks:
             m = rasterize_mask(self.polygons, self.level_dimensions[level], self.level_dimensions[0])
-            self._masks[level] = torch.from_numpy(m).to(self.device)
+            h, w = m.shape
+            wp = (w + 15) // 16 * 16  # zero-padded row pitch: 16-byte loads in hipac_mask_cells
+            buf = torch.zeros((h, wp), dtype=torch.uint8, device=self.device)
+            buf[:, :w] = torch.from_numpy(m).to(self.device)
+            self._masks[level] = buf
         return self._masks[level]
 
 
@@ -218,7 +222,7 @@ class LevelWindows:
         if mask is None:
             self.labels = torch.zeros((self.xy.shape[0],), dtype=torch.uint8, device=slide.device)
         elif on_lattice:
-            self.labels = capi.window_labels_cells(capi.mask_cells(mask), width, height, self.xy, self.P)
+            self.labels = capi.window_labels_cells(capi.mask_cells(mask, width=width), width, height, self.xy, self.P)
         else:
             self.labels = capi.window_labels(mask, self.xy, self.P)
 
@@ -271,54 +275,96 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order."""
     has_fc = net.num_classes > 0 and want_logits
     dev = slide.device
-    # pass 1: every extractor decision of every level (whole-level kernels; one host sync per level
-    # for the kept count)
-    lws, kepts = [], []
-    for level in levels:
-        st = stride(level) if callable(stride) else stride
-        lw = LevelWindows(slide, level, st)
-        lws.append(lw)
-        kepts.append(lw.kept_index())
-    n_total = sum(int(k.shape[0]) for k in kepts)
-    if n_total == 0:
-        return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
-    metas = torch.cat([lw.meta(k) for lw, k in zip(lws, kepts) if k.shape[0]])
-    # pass 2: ONE uint8 batch buffer for the whole slide; the resize/gather of the windows runs on a
-    # side stream in pieces of `batch_windows`, the ResNet follows it on the caller's stream in batches of
-    # FWD patches (zero-copy slices; the late layers need thousands of patches per launch)
-    FWD = 8192
-    buf = torch.empty((n_total, 224, 224, 3), dtype=torch.uint8, device=dev)
-    feats = torch.empty((n_total, 512), dtype=torch.float32, device=dev)
-    logits = torch.empty((n_total, net.num_classes), dtype=torch.float32, device=dev) if has_fc else None
-    preds = torch.empty((n_total,), dtype=torch.int64, device=dev) if has_fc else None
+    levels = list(levels)
+    FWD = 8192  # patches per forward: the late layers need thousands of patches per launch
+
+    def stride_of(level):
+        return stride(level) if callable(stride) else stride
+
+    # Schedule: the level with the most windows (normally level 0) costs most to decide and gather, so
+    # the OTHER levels go first: their windows are decided (whole-level kernels), gathered into one uint8
+    # batch buffer on a side stream and the ResNet starts on them on the caller's stream; the big level's
+    # decisions and gathers then run on the side stream underneath those forwards.  Batches are zero-copy
+    # slices of the batch buffers; results are put back into level-major order at the end.
+    big = max(levels, key=lambda lv: slide.level_dimensions[lv][0] * slide.level_dimensions[lv][1])
+    small = [lv for lv in levels if lv != big]
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
     side.wait_stream(main)
-    marks = []  # (patches gathered so far, event)
-    done = 0
+    out_chunks = []   # (f, l, p) per forward, processing order
+    proc_meta = {}    # level -> (meta rows, count), to restore level-major order
+    marks = []        # per buffer: list of (patches gathered so far, event)
+
+    def gather_into(buf, start, lw, kept, mk):
+        done = start
+        for i0 in range(0, kept.shape[0], batch_windows):
+            idx = kept[i0:i0 + batch_windows]
+            lw.patches(idx, out=buf[done:done + idx.shape[0]])
+            done += idx.shape[0]
+            ev = torch.cuda.Event()
+            ev.record(side)
+            mk.append((done, ev))
+        return done
+
+    def forward_range(buf, mk, lo, hi):
+        mi = 0
+        while lo < hi:
+            end = min(hi, lo + FWD)
+            while mk[mi][0] < end:
+                mi += 1
+            main.wait_event(mk[mi][1])
+            out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
+            lo = end
+
     with torch.cuda.stream(side):
-        for lw, kept in zip(lws, kepts):
-            for i0 in range(0, kept.shape[0], batch_windows):
-                idx = kept[i0:i0 + batch_windows]
-                lw.patches(idx, out=buf[done:done + idx.shape[0]])
-                done += idx.shape[0]
+        lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in small]
+        kepts = [lw.kept_index() for lw in lws]  # host syncs with the side stream only
+    n_small = sum(int(k.shape[0]) for k in kepts)
+    for lv, lw, k in zip(small, lws, kepts):
+        proc_meta[lv] = (lw.meta(k), int(k.shape[0]))
+    carry = n_small % FWD if n_small else 0
+    buf_s, mk_s = None, []
+    if n_small:
+        buf_s = torch.empty((n_small, 224, 224, 3), dtype=torch.uint8, device=dev)
+        buf_s.record_stream(side)
+        with torch.cuda.stream(side):
+            done = 0
+            for lw, k in zip(lws, kepts):
+                done = gather_into(buf_s, done, lw, k, mk_s)
+        forward_range(buf_s, mk_s, 0, n_small - carry)  # full batches; the remainder joins the big level
+    with torch.cuda.stream(side):
+        lwb = LevelWindows(slide, big, stride_of(big))
+        kb = lwb.kept_index()
+    nb = int(kb.shape[0])
+    proc_meta[big] = (lwb.meta(kb), nb)
+    if carry + nb:
+        buf_b = torch.empty((carry + nb, 224, 224, 3), dtype=torch.uint8, device=dev)
+        buf_b.record_stream(side)
+        mk_b = []
+        with torch.cuda.stream(side):
+            if carry:
+                buf_b[:carry].copy_(buf_s[n_small - carry:])
                 ev = torch.cuda.Event()
                 ev.record(side)
-                marks.append((done, ev))
-    buf.record_stream(side)
-    scored, mi = 0, 0
-    while scored < n_total:
-        end = min(n_total, scored + FWD)
-        while marks[mi][0] < end:
-            mi += 1
-        main.wait_event(marks[mi][1])
-        f, l, p = net.forward(buf[scored:end], want_feats=True, want_logits=has_fc, want_labels=has_fc)
-        feats[scored:end] = f
-        if has_fc:
-            logits[scored:end] = l
-            preds[scored:end] = p
-        scored = end
-    return feats, logits, preds, metas
+                mk_b.append((carry, ev))
+            gather_into(buf_b, carry, lwb, kb, mk_b)
+        forward_range(buf_b, mk_b, 0, carry + nb)
+    main.wait_stream(side)
+    n_total = n_small + nb
+    if n_total == 0:
+        return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
+    feats_p = torch.cat([c[0] for c in out_chunks])
+    logits_p = torch.cat([c[1] for c in out_chunks]) if has_fc else None
+    preds_p = torch.cat([c[2] for c in out_chunks]) if has_fc else None
+    # processing order = small levels (as listed), then the big one -> level-major order of `levels`
+    starts, o = {}, 0
+    for lv in small + [big]:
+        starts[lv] = o
+        o += proc_meta[lv][1]
+    perm = torch.cat([torch.arange(starts[lv], starts[lv] + proc_meta[lv][1], device=dev) for lv in levels])
+    metas = torch.cat([proc_meta[lv][0] for lv in levels])
+    return (feats_p.index_select(0, perm), logits_p.index_select(0, perm) if has_fc else None,
+            preds_p.index_select(0, perm) if has_fc else None, metas)
 
 
 def save_patch_pngs(slide: DeviceSlide, level: int, out_dir: str, stride: Optional[int] = None) -> int:
