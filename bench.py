@@ -294,9 +294,13 @@ def run_wsi(args, rank, world, dev):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 3
         gbs = w0 * h0 * 3 / (ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath) and side == 50000:  # the PMC passes were taken on the default 50 000^2 slide
+            traffic = json.load(open(tpath)).get("wsi_level0_planes")
         extra["roofline"] = {"bound": "hbm", "kernel": "hipac_level_build_planes[level 0: hpass_kernel<8> + vpass_kernel<8>]",
                              "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                             "traffic": None, "launch_ms": ms, "bytes_per_launch": w0 * h0 * 3}
+                             "traffic": traffic, "launch_ms": ms, "bytes_per_launch": w0 * h0 * 3}
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline_wsi()
     return {**extra,
