@@ -115,6 +115,26 @@ class DeviceSlide:
             s.polygons = synth.synth_polygons(width, height, seed=seed)
         return s
 
+    @classmethod
+    def from_tiff(cls, path: str, device="cuda", n_levels: int = 4, name: Optional[str] = None, workers: int = 16):
+        """Open a tiled pyramidal TIFF / BigTIFF (the CAMELYON16 container; ``openslide.OpenSlide(path)`` in
+        the reference, src/main.py:650) and bring its first ``n_levels`` levels into HBM
+        (``tiff_pyramid.TiffPyramid``: tiles decoded on host threads, copied band by band)."""
+        from .tiff_pyramid import TiffPyramid
+
+        tp = TiffPyramid(path)
+        dev = torch.device(device)
+        s = cls.__new__(cls)
+        s.name = name or os.path.splitext(os.path.basename(path))[0]
+        use = list(range(min(n_levels, tp.level_count)))
+        s.level_dimensions = tuple(tp.level_dimensions[i] for i in use)
+        s.level_downsamples = tuple(tp.level_downsamples[i] for i in use)
+        s.levels = [t for t, _ in tp.to_device_levels(dev, use, workers)]
+        s.device = dev
+        s.polygons = None
+        s._masks = {}
+        return s
+
     def mask(self, level: int) -> Optional[torch.Tensor]:
         if self.polygons is None:
             return None

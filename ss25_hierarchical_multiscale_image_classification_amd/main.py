@@ -3,7 +3,8 @@
 ``--train``, ``--train_strategy``, ``--strategy {balanced,weighted_loss,self_supervised}``.
 
 Layout under ``--data_root`` (default ``./data/camelyon16``, README.md:142-164):
-    train/img/<slide>.{npz,tif}      slides   (.npz: keys level0..levelN uint8[H,W,3])
+    train/img/<slide>.{npz,tif}      slides   (.tif: tiled pyramidal TIFF / BigTIFF, levels 0-3 are used;
+                                              .npz: keys level0..levelN uint8[H,W,3])
     train/mask/annotations/<slide>.xml
     patches/level_L/<slide>/...      extractor output
 Outputs of ``--extract_features`` are written to the current directory exactly like
@@ -85,9 +86,9 @@ def open_slides(args):
             z = np.load(os.path.join(img_dir, file))
             levels = [torch.from_numpy(z[f"level{i}"]) for i in range(len(z.files)) if f"level{i}" in z.files]
             slide = DeviceSlide(levels, name=stem)
-        elif ext == ".tif":
-            raise SystemExit(f"[ERROR] {file}: reading TIFF pyramids needs openslide, which is not available "
-                             "here; convert the slide to .npz levels or use --synthetic")
+        elif ext in (".tif", ".tiff"):
+            # tiled pyramidal TIFF / BigTIFF (the CAMELYON16 container): own reader, openslide is not needed
+            slide = DeviceSlide.from_tiff(os.path.join(img_dir, file), name=stem)
         else:
             continue
         xml = os.path.join(ann_dir, stem + ".xml")

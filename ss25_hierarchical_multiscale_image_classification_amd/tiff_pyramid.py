@@ -1,0 +1,311 @@
+"""Tiled pyramidal TIFF / BigTIFF reader feeding the device pyramid.
+
+The reference opens CAMELYON16 slides with openslide (src/main.py:650-655:
+``OpenSlide(path)``, ``level_dimensions``, ``level_downsamples``) and pulls every window
+through ``read_region(location, level, size)`` (:693-697).  openslide is not available in
+this image, so this module reads the container itself: classic TIFF and BigTIFF, tiled
+IFDs, 8-bit RGB, compression none / deflate / LZW-free JPEG (old-style excluded), one
+pyramid level per full-resolution or reduced-resolution tiled IFD, largest first
+(the "generic tiled TIFF" layout of the CAMELYON16 files).
+
+Tiles are decoded on host threads (Pillow's JPEG / zlib decoders release the GIL) in row
+bands and copied band by band into the level's HBM tensor, so the host never holds more
+than one band of one level.  Semantics kept from openslide:
+  * ``level_dimensions`` / ``level_downsamples`` (downsample = level-0 width / level width),
+  * pixels of missing tiles (byte count 0) are transparent black, which the reference's
+    ``.convert("RGB")`` turns into (0,0,0) -- here they are written as 0,
+  * ``read_region`` (host, RGBA uint8, out-of-bounds = transparent black) for small
+    regions and for tests.
+"""
+from __future__ import annotations
+
+import io
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 6: ("b", 1), 7: ("B", 1), 8: ("h", 2),
+          9: ("i", 4), 10: ("ii", 8), 11: ("f", 4), 12: ("d", 8), 16: ("Q", 8), 17: ("q", 8), 18: ("Q", 8)}
+
+
+class TiffError(ValueError):
+    pass
+
+
+@dataclass
+class TiffLevel:
+    width: int
+    height: int
+    tile_w: int
+    tile_h: int
+    compression: int
+    photometric: int
+    samples: int
+    offsets: Sequence[int]
+    counts: Sequence[int]
+    jpeg_tables: Optional[bytes]
+    subfile_type: int
+
+    @property
+    def tiles_across(self) -> int:
+        return (self.width + self.tile_w - 1) // self.tile_w
+
+    @property
+    def tiles_down(self) -> int:
+        return (self.height + self.tile_h - 1) // self.tile_h
+
+
+def _parse_ifds(buf) -> List[dict]:
+    bo = {b"II": "<", b"MM": ">"}.get(bytes(buf[:2]))
+    if bo is None:
+        raise TiffError("not a TIFF file")
+    magic = struct.unpack(bo + "H", buf[2:4])[0]
+    if magic == 42:
+        big, off = False, struct.unpack(bo + "I", buf[4:8])[0]
+    elif magic == 43:
+        big, off = True, struct.unpack(bo + "Q", buf[8:16])[0]
+    else:
+        raise TiffError(f"bad TIFF magic {magic}")
+    ifds = []
+    seen = set()
+    while off and off not in seen and len(ifds) < 64:
+        seen.add(off)
+        if big:
+            (n,) = struct.unpack(bo + "Q", buf[off:off + 8])
+            pos, esz, cw = off + 8, 20, 8
+        else:
+            (n,) = struct.unpack(bo + "H", buf[off:off + 2])
+            pos, esz, cw = off + 2, 12, 4
+        tags = {}
+        for i in range(n):
+            e = buf[pos + i * esz: pos + (i + 1) * esz]
+            tag, typ = struct.unpack(bo + "HH", e[:4])
+            (cnt,) = struct.unpack(bo + ("Q" if big else "I"), e[4:4 + cw])
+            if typ not in _TYPES:
+                continue
+            fmt, sz = _TYPES[typ]
+            nbytes = cnt * sz
+            if nbytes <= cw:
+                raw = bytes(e[4 + cw:4 + cw + nbytes])
+            else:
+                (voff,) = struct.unpack(bo + ("Q" if big else "I"), e[4 + cw:4 + 2 * cw])
+                raw = bytes(buf[voff:voff + nbytes])
+            if typ in (2, 7):
+                tags[tag] = raw
+            elif typ in (5, 10):
+                vals = struct.unpack(bo + fmt[0] * (2 * cnt), raw)
+                tags[tag] = [vals[2 * j] / max(1, vals[2 * j + 1]) for j in range(cnt)]
+            else:
+                tags[tag] = list(struct.unpack(bo + fmt * cnt, raw))
+        ifds.append(tags)
+        nxt = buf[pos + n * esz: pos + n * esz + cw]
+        (off,) = struct.unpack(bo + ("Q" if big else "I"), nxt)
+    return ifds
+
+
+def _adobe_rgb_marker() -> bytes:
+    # APP14 "Adobe" with transform = 0: the three components are RGB, not YCbCr
+    return b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00"
+
+
+class TiffPyramid:
+    """Tiled TIFF pyramid.  ``level_dimensions`` / ``level_downsamples`` as in openslide."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r")
+        self._buf = memoryview(self._mm)
+        levels = []
+        for t in _parse_ifds(self._buf):
+            if 322 not in t or 324 not in t:  # not tiled (label / macro / thumbnail strips): not a pyramid level
+                continue
+            bits = t.get(258, [8])
+            spp = t.get(277, [1])[0]
+            if any(b != 8 for b in bits) or spp not in (3, 4) or t.get(284, [1])[0] != 1:
+                continue
+            lv = TiffLevel(width=t[256][0], height=t[257][0], tile_w=t[322][0], tile_h=t[323][0],
+                           compression=t.get(259, [1])[0], photometric=t.get(262, [2])[0], samples=spp,
+                           offsets=t[324], counts=t[325], jpeg_tables=t.get(347), subfile_type=t.get(254, [0])[0])
+            if lv.compression not in (1, 7, 8, 32946):
+                raise TiffError(f"unsupported tile compression {lv.compression} (none, JPEG and deflate are read)")
+            levels.append(lv)
+        if not levels:
+            raise TiffError("no tiled 8-bit RGB image directory found")
+        levels.sort(key=lambda l: -l.width * l.height)
+        self.levels: List[TiffLevel] = levels
+        self.level_count = len(levels)
+        self.level_dimensions = tuple((l.width, l.height) for l in levels)
+        self.dimensions = self.level_dimensions[0]
+        self.level_downsamples = tuple(self.dimensions[0] / l.width for l in levels)
+
+    # ---- tiles -------------------------------------------------------------------------
+    def _decode_tile(self, lv: TiffLevel, index: int) -> Optional[np.ndarray]:
+        """uint8[tile_h, tile_w, 3] or None for a missing tile."""
+        off, cnt = lv.offsets[index], lv.counts[index]
+        if cnt == 0:
+            return None
+        raw = bytes(self._buf[off:off + cnt])
+        if lv.compression == 1:
+            a = np.frombuffer(raw, np.uint8)
+        elif lv.compression in (8, 32946):
+            a = np.frombuffer(zlib.decompress(raw), np.uint8)
+        else:
+            from PIL import Image
+
+            data = raw
+            if lv.jpeg_tables:
+                tb = lv.jpeg_tables
+                data = tb[:-2] + raw[2:] if tb[-2:] == b"\xff\xd9" and raw[:2] == b"\xff\xd8" else raw
+            if lv.photometric == 2:  # RGB stored in the JPEG: keep Pillow from applying YCbCr -> RGB
+                data = data[:2] + _adobe_rgb_marker() + data[2:]
+            im = Image.open(io.BytesIO(data))
+            im.load()
+            a = np.asarray(im.convert("RGB"))
+            if a.shape[0] != lv.tile_h or a.shape[1] != lv.tile_w:
+                raise TiffError("JPEG tile size does not match the directory")
+            return a
+        a = a[: lv.tile_h * lv.tile_w * lv.samples].reshape(lv.tile_h, lv.tile_w, lv.samples)
+        return a[:, :, :3]
+
+    def read_band(self, level: int, tile_row: int, pool: Optional[ThreadPoolExecutor] = None) -> np.ndarray:
+        """uint8[rows, width, 3] of one row of tiles (clipped to the level), missing tiles = 0."""
+        lv = self.levels[level]
+        y0 = tile_row * lv.tile_h
+        rows = min(lv.tile_h, lv.height - y0)
+        band = np.zeros((rows, lv.width, 3), np.uint8)
+        idx = [tile_row * lv.tiles_across + tx for tx in range(lv.tiles_across)]
+        tiles = list(pool.map(lambda i: self._decode_tile(lv, i), idx)) if pool else [self._decode_tile(lv, i) for i in idx]
+        for tx, t in enumerate(tiles):
+            if t is None:
+                continue
+            x0 = tx * lv.tile_w
+            cols = min(lv.tile_w, lv.width - x0)
+            band[:, x0:x0 + cols] = t[:rows, :cols]
+        return band
+
+    def read_region(self, location: Tuple[int, int], level: int, size: Tuple[int, int]) -> np.ndarray:
+        """openslide semantics: ``location`` in level-0 coordinates, ``size`` in level pixels;
+        returns uint8[h, w, 4] RGBA, transparent black outside the level and in missing tiles."""
+        lv = self.levels[level]
+        ds = self.level_downsamples[level]
+        x0, y0 = int(location[0] / ds), int(location[1] / ds)
+        w, h = size
+        out = np.zeros((h, w, 4), np.uint8)
+        for ty in range(max(0, y0 // lv.tile_h), min(lv.tiles_down, (y0 + h - 1) // lv.tile_h + 1)):
+            for tx in range(max(0, x0 // lv.tile_w), min(lv.tiles_across, (x0 + w - 1) // lv.tile_w + 1)):
+                t = self._decode_tile(lv, ty * lv.tiles_across + tx)
+                if t is None:
+                    continue
+                gx0, gy0 = tx * lv.tile_w, ty * lv.tile_h
+                ax0, ay0 = max(gx0, x0), max(gy0, y0)
+                ax1 = min(gx0 + lv.tile_w, lv.width, x0 + w)
+                ay1 = min(gy0 + lv.tile_h, lv.height, y0 + h)
+                if ax1 <= ax0 or ay1 <= ay0:
+                    continue
+                out[ay0 - y0:ay1 - y0, ax0 - x0:ax1 - x0, :3] = t[ay0 - gy0:ay1 - gy0, ax0 - gx0:ax1 - gx0]
+                out[ay0 - y0:ay1 - y0, ax0 - x0:ax1 - x0, 3] = 255
+        return out
+
+    # ---- device pyramid ----------------------------------------------------------------
+    def to_device_levels(self, device="cuda", levels: Optional[Sequence[int]] = None, workers: int = 16):
+        """Decode on host threads, band by band, into uint8[H, Wpad, 3] HBM tensors (row pitch a multiple
+        of 16 pixels, as ``DeviceSlide`` lays levels out).  Returns a list of (tensor, width)."""
+        import torch
+
+        out = []
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for li in (range(self.level_count) if levels is None else levels):
+                lv = self.levels[li]
+                wp = (lv.width + 15) // 16 * 16
+                dev = torch.zeros((lv.height, wp, 3), dtype=torch.uint8, device=device)
+                for tr in range(lv.tiles_down):
+                    band = torch.from_numpy(self.read_band(li, tr, pool))
+                    if dev.is_cuda:
+                        band = band.pin_memory()
+                    y0 = tr * lv.tile_h
+                    dev[y0:y0 + band.shape[0], :lv.width].copy_(band, non_blocking=False)
+                out.append((dev, lv.width))
+        return out
+
+
+def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, compression: str = "jpeg",
+                     quality: int = 90, bigtiff: bool = False, missing: Sequence[Tuple[int, int, int]] = ()):
+    """Minimal writer of a tiled pyramid (tests and synthetic data only): ``levels`` are uint8[H,W,3]
+    arrays, largest first.  compression: "none" | "deflate" | "jpeg" (YCbCr, abbreviated tables are not
+    used: every tile is a complete JPEG).  ``missing``: (level, ty, tx) tiles written with byte count 0."""
+    from PIL import Image
+
+    comp = {"none": 1, "deflate": 8, "jpeg": 7}[compression]
+    bo = "<"
+    blobs, ifd_specs = [], []
+    pos = 16 if bigtiff else 8
+    for li, img in enumerate(levels):
+        h, w = img.shape[:2]
+        ta, td = (w + tile - 1) // tile, (h + tile - 1) // tile
+        offs, cnts = [], []
+        for ty in range(td):
+            for tx in range(ta):
+                if (li, ty, tx) in missing:
+                    offs.append(0), cnts.append(0)
+                    continue
+                t = np.zeros((tile, tile, 3), np.uint8)
+                part = img[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+                t[:part.shape[0], :part.shape[1]] = part
+                if comp == 1:
+                    data = t.tobytes()
+                elif comp == 8:
+                    data = zlib.compress(t.tobytes(), 6)
+                else:
+                    bio = io.BytesIO()
+                    Image.fromarray(t, "RGB").save(bio, "JPEG", quality=quality)
+                    data = bio.getvalue()
+                offs.append(pos), cnts.append(len(data))
+                blobs.append(data)
+                pos += len(data)
+        ifd_specs.append((w, h, ta * td, offs, cnts))
+    out = bytearray()
+    # data area first, then IFDs (offsets known up front)
+    body = b"".join(blobs)
+    ifd_pos = (16 if bigtiff else 8) + len(body)
+    chunks = []
+    cur = ifd_pos
+    for li, (w, h, nt, offs, cnts) in enumerate(ifd_specs):
+        photometric = 6 if comp == 7 else 2
+        entries = [(254, 4, [1 if li else 0]), (256, 4, [w]), (257, 4, [h]), (258, 3, [8, 8, 8]), (259, 3, [comp]),
+                   (262, 3, [photometric]), (277, 3, [3]), (284, 3, [1]), (322, 4, [tile]), (323, 4, [tile]),
+                   (324, 16 if bigtiff else 4, offs), (325, 16 if bigtiff else 4, cnts)]
+        n = len(entries)
+        esz, cw = (20, 8) if bigtiff else (12, 4)
+        head = 8 if bigtiff else 2
+        ifd_len = head + n * esz + cw
+        extra = bytearray()
+        ent_bytes = bytearray()
+        for tag, typ, vals in entries:
+            fmt, sz = _TYPES[typ]
+            raw = struct.pack(bo + fmt * len(vals), *vals)
+            ent_bytes += struct.pack(bo + "HH", tag, typ) + struct.pack(bo + ("Q" if bigtiff else "I"), len(vals))
+            if len(raw) <= cw:
+                ent_bytes += raw.ljust(cw, b"\0")
+            else:
+                ent_bytes += struct.pack(bo + ("Q" if bigtiff else "I"), cur + ifd_len + len(extra))
+                extra += raw
+                if len(extra) % 2:
+                    extra += b"\0"
+        nxt = cur + ifd_len + len(extra) if li + 1 < len(ifd_specs) else 0
+        blob = (struct.pack(bo + "Q", n) if bigtiff else struct.pack(bo + "H", n)) + bytes(ent_bytes) + \
+            struct.pack(bo + ("Q" if bigtiff else "I"), nxt) + bytes(extra)
+        chunks.append(blob)
+        cur += len(blob)
+    if bigtiff:
+        out += b"II" + struct.pack(bo + "HHH", 43, 8, 0) + struct.pack(bo + "Q", ifd_pos)
+    else:
+        out += b"II" + struct.pack(bo + "H", 42) + struct.pack(bo + "I", ifd_pos)
+    out += body
+    for c in chunks:
+        out += c
+    with open(path, "wb") as f:
+        f.write(out)

@@ -86,3 +86,21 @@ def test_cli_patch_then_extract_features(tmp_path, monkeypatch):
     assert feats.shape == (len(pngs), 512) and feats.dtype == np.float32
     assert labels.shape == (len(pngs),) and labels.dtype == np.int64 and len(paths) == len(pngs)
     assert np.isfinite(feats).all() and float(np.abs(feats).max()) > 0
+
+
+def test_tiff_slide_scans_like_the_same_pixels_from_memory(tmp_path):
+    # a tiled (deflate, lossless) TIFF pyramid read through tiff_pyramid -> DeviceSlide.from_tiff gives the
+    # same extractor decisions and resized patches as the same levels handed over as tensors
+    from ss25_hierarchical_multiscale_image_classification_amd import tiff_pyramid as tp
+
+    ref = extract.DeviceSlide.synthetic(2300, 1900, seed=4, with_polygons=False)
+    levels = [l[:, :w].cpu().numpy() for l, (w, _) in zip(ref.levels, ref.level_dimensions)]
+    path = str(tmp_path / "slide_007.tif")
+    tp.write_tiled_tiff(path, levels, tile=512, compression="deflate", bigtiff=True)
+    got = extract.DeviceSlide.from_tiff(path)
+    assert got.name == "slide_007" and got.level_dimensions == ref.level_dimensions
+    for level in (1, 2, 3):
+        a, b = extract.LevelWindows(ref, level), extract.LevelWindows(got, level)
+        assert torch.equal(a.xy, b.xy) and torch.equal(a.keep, b.keep) and torch.equal(a.sums, b.sums)
+        k = a.kept_index()
+        assert torch.equal(a.patches(k), b.patches(k))

@@ -1,0 +1,74 @@
+"""CPU: the tiled-TIFF pyramid reader (openslide stand-in for real slides) against Pillow's
+own TIFF reader (libtiff) on files written by the minimal writer, and read_region's openslide semantics."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from ss25_hierarchical_multiscale_image_classification_amd import tiff_pyramid as tp
+
+
+def pyramid(seed=0, w=700, h=530):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255 // w), (yy * 255 // h), ((xx + yy) % 256)], -1).astype(np.int32)
+    l0 = np.clip(base + rng.randint(-20, 21, base.shape), 0, 255).astype(np.uint8)
+    l1 = l0[::2, ::2].copy()
+    l2 = l1[::2, ::2].copy()
+    return [l0, l1, l2]
+
+
+@pytest.mark.parametrize("compression,bigtiff", [("none", False), ("deflate", False), ("deflate", True), ("jpeg", False),
+                                                  ("jpeg", True)])
+def test_levels_match_pillow_reader(tmp_path, compression, bigtiff):
+    levels = pyramid()
+    path = str(tmp_path / "s.tif")
+    tp.write_tiled_tiff(path, levels, tile=256, compression=compression, bigtiff=bigtiff)
+    slide = tp.TiffPyramid(path)
+    assert slide.level_count == 3
+    assert slide.level_dimensions == tuple((l.shape[1], l.shape[0]) for l in levels)
+    assert slide.level_downsamples[0] == 1.0 and abs(slide.level_downsamples[1] - 2.0) < 0.01
+    im = Image.open(path)  # Pillow / libtiff: an independent reader of the same bytes
+    for li, ref in enumerate(levels):
+        im.seek(li)
+        pil = np.asarray(im.convert("RGB"))
+        lv = slide.levels[li]
+        got = np.concatenate([slide.read_band(li, tr) for tr in range(lv.tiles_down)], 0)
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got, pil)          # same pixels as libtiff decodes
+        if compression != "jpeg":
+            np.testing.assert_array_equal(got, ref)      # lossless: the written pixels
+
+
+def test_read_region_semantics_and_missing_tiles(tmp_path):
+    levels = pyramid(1)
+    path = str(tmp_path / "m.tif")
+    tp.write_tiled_tiff(path, levels, tile=256, compression="deflate", missing=[(0, 1, 1)])
+    slide = tp.TiffPyramid(path)
+    # inside: RGBA with opaque alpha, pixels of the level
+    r = slide.read_region((40, 30), 0, (100, 80))
+    np.testing.assert_array_equal(r[..., :3], levels[0][30:110, 40:140])
+    assert (r[..., 3] == 255).all()
+    # location is in LEVEL-0 coordinates, size in level pixels (src/main.py:693-697)
+    r1 = slide.read_region((200, 100), 1, (50, 40))
+    np.testing.assert_array_equal(r1[..., :3], levels[1][50:90, 100:150])
+    # beyond the right / bottom edge: transparent black (the reference's convert("RGB") makes it (0,0,0))
+    w, h = slide.level_dimensions[0]
+    e = slide.read_region((w - 10, h - 5), 0, (32, 32))
+    np.testing.assert_array_equal(e[:5, :10, :3], levels[0][h - 5:, w - 10:])
+    assert (e[5:, :, :] == 0).all() and (e[:, 10:, :] == 0).all()
+    # a missing tile (byte count 0) is transparent black
+    m = slide.read_region((256, 256), 0, (256, 256))
+    assert (m == 0).all()
+    band = slide.read_band(0, 1)
+    assert (band[:, 256:512] == 0).all() and (band[:, :256] == levels[0][256:512, :256]).all()
+
+
+def test_rejects_untiled_and_garbage(tmp_path):
+    p = tmp_path / "strip.tif"
+    Image.fromarray(np.zeros((40, 40, 3), np.uint8)).save(str(p))  # Pillow writes strips, not tiles
+    with pytest.raises(tp.TiffError):
+        tp.TiffPyramid(str(p))
+    q = tmp_path / "x.tif"
+    q.write_bytes(b"not a tiff at all")
+    with pytest.raises(tp.TiffError):
+        tp.TiffPyramid(str(q))
