@@ -263,3 +263,25 @@ def test_large_ragged_batches_two_lanes_default_schedule(n):
     assert torch.equal(f, torch.cat([p[0] for p in pieces]))
     assert torch.equal(l, torch.cat([p[1] for p in pieces]))
     assert torch.equal(lab, torch.cat([p[2] for p in pieces]))
+
+
+def test_forward_is_hip_graph_capturable():
+    # the library only enqueues work on the caller's stream (plus its fork/join lane): a forward can be
+    # captured into a HIP graph and replayed; results equal the eager launch bit for bit
+    sd = synth.seeded_resnet18_state_dict(1, num_classes=2)
+    net = capi.PackedResNet18(sd, precision="bf16")
+    u8 = synth.synth_patches_u8(40, seed=2, device="cuda")
+    f0, l0, p0 = net.forward(u8, want_logits=True, want_labels=True)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        net.forward(u8, want_logits=True, want_labels=True)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            fg, lg, pg = net.forward(u8, want_logits=True, want_labels=True)
+    u8.copy_(synth.synth_patches_u8(40, seed=3, device="cuda"))  # new pixels in the captured input buffer
+    g.replay()
+    torch.cuda.synchronize()
+    f1, l1, p1 = net.forward(u8, want_logits=True, want_labels=True)
+    assert torch.equal(fg, f1) and torch.equal(lg, l1) and torch.equal(pg, p1)
+    assert not torch.equal(f0, f1)
