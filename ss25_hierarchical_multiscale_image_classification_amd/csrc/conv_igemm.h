@@ -630,7 +630,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 
   // ---- consumer side: slot of this lane's two output pixels for tap (0, centre column) ----
   int q0[MTW];
-  bool edgeL[MTW], edgeR[MTW], edgeT[MTW], edgeB[MTW];
+  // bit 0: x == 0, bit 1: x == W-1, bit 2: y == 0, bit 3: y == H-1.  One register per sub-tile and one AND
+  // per tap: four bool arrays tested against the runtime (kh, kw) cost 7-13 % of the kernel (compare /
+  // mask-combine chains in the tap loop)
+  int eflags[MTW];
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
     int m = m0 + wm * (MTW * 32) + i * 32 + r;
@@ -639,10 +642,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     const int rem = m - b * (H * W);
     const int y = rem / W, x = rem - y * W;
     q0[i] = m - mstart + 2;                       // tap (kh,kw) -> q0 + (kh-1)*W + kw - 1
-    edgeL[i] = x == 0;
-    edgeR[i] = x == W - 1;
-    edgeT[i] = y == 0;
-    edgeB[i] = y == H - 1;
+    eflags[i] = (x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0);
   }
   const int sw_w = (r >> 1) & 7;
   int rdw[4], ck[4];
@@ -720,11 +720,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+      const int tapmask = (kw == 0 ? 1 : 0) | (kw == 2 ? 2 : 0) | (kh == 0 ? 4 : 0) | (kh == 2 ? 8 : 0);  // uniform
       int abase[MTW], asw[MTW];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        const bool off_img = (kw == 0 && edgeL[i]) || (kw == 2 && edgeR[i]) || (kh == 0 && edgeT[i]) ||
-                             (kh == 2 && edgeB[i]);
+        const bool off_img = (eflags[i] & tapmask) != 0;
         // out-of-image taps read a zero pixel: slot 0 or 1 by the parity of the slot the lane would
         // have read, at the chunk position its swizzle selects -- i.e. the SAME 16-byte bank group
         // as the in-image address, so redirected lanes never collide with their neighbours
