@@ -528,6 +528,9 @@ static __device__ unsigned long long g_halo_stamps[8];
 #ifndef HIPAC_C64_PF
 #define HIPAC_C64_PF 2  // layer1 kernel: LDS fragment reads run this many k16 steps ahead of their MFMAs
 #endif
+#ifndef HIPAC_HALO_TAP_UNROLL
+#define HIPAC_HALO_TAP_UNROLL 3  // taps per unrolled group: 3 makes kw a constant (9 is slower: 2x, code size)
+#endif
 #ifndef HIPAC_HALO_W_ISSUE_KK
 #define HIPAC_HALO_W_ISSUE_KK 1  // k16 sub-step after whose MFMAs the next weight tile is requested (-1: step start)
 #endif
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
       issue_band(cc);
     }
-#pragma unroll 1
+#pragma unroll HIPAC_HALO_TAP_UNROLL
     for (int tap = 0; tap < 9; ++tap, ++s) {
       // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
       if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
