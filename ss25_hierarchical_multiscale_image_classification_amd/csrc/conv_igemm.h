@@ -223,6 +223,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
 // Grid is 1-D and XCD-aware: the channel tiles of one pixel tile get consecutive slots
 // on ONE XCD (ids congruent mod 8 share an XCD), so the shared A rows hit that XCD's L2.
 // ---------------------------------------------------------------------------------------
+// Buffer-descriptor LDS-DMA: 16 bytes per lane from base + voffset (VGPR, range-checked against the
+// descriptor's size: out of range reads as zeros) + soffset (SGPR, not range-checked) into
+// lds_base + lane * 16.  The builtins exist only in the device pass; the host pass needs the kernel
+// templates to parse so that their launch stubs are emitted.
+#if defined(__HIP_DEVICE_COMPILE__)
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buffer_load_lds16(rsrc_t rs, void* lds, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
+}
+#else
+struct rsrc_t {};
+__device__ inline rsrc_t make_rsrc(const void*, int) { return {}; }
+__device__ inline void buffer_load_lds16(rsrc_t, void*, int, int) {}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
@@ -318,22 +336,22 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
+  // LDS-DMA through buffer descriptors: a tap that leaves the image (or a row beyond M) gets an offset
+  // past the descriptor's range and reads as zeros -- no zero-page select, no 64-bit address arithmetic
+  const rsrc_t in_rsrc = make_rsrc(in_b, (M / (HO * WO)) * (HI * WI * CIN * 2));
+  const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
+  const rsrc_t wp_rsrc = make_rsrc(PROJ ? wp_b : w_b, COUT * CIN * 2);
   auto issue = [&](int tap, int tapoff_bytes, int kofs_bytes, int stage, bool proj) {
     unsigned char* sbase = ring + stage * STAGE;
     static_for<APW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       const bool ok = (a_mask[i] >> tap) & 1u;
-      const char* src = ok ? in_b + (a_off[i] + tapoff_bytes) : zsrc;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave + NWAVES * i) * 1024), 16, 0, 0);
+      buffer_load_lds16(in_rsrc, sbase + (wave + NWAVES * i) * 1024, ok ? a_off[i] + tapoff_bytes : (int)0x80000000, 0);
     });
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      const char* src = w_b + (w_off[i] + kofs_bytes);
-      if constexpr (PROJ) {
-        if (proj) src = wp_b + (wp_off[i] + kofs_bytes);
-      }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 128 + (wave + NWAVES * i) * 1024), 16, 0,
-                                       0);
+      if (PROJ && proj) buffer_load_lds16(wp_rsrc, sbase + BM * 128 + (wave + NWAVES * i) * 1024, wp_off[i], kofs_bytes);
+      else buffer_load_lds16(w_rsrc, sbase + BM * 128 + (wave + NWAVES * i) * 1024, w_off[i], kofs_bytes);
     });
   };
 
@@ -621,13 +639,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
     const int row = (wave + 4 * i) * 8 + prow;
     w_off[i] = ((n0 + row) * KTOT + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
   }
+  // weight DMA through a buffer descriptor: per-lane 32-bit row offset in a VGPR (computed once per
+  // tile), the tap / chunk offset in an SGPR -- no per-piece address arithmetic in the tap loop
+  const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
   auto issue_w = [&](int step, int slot_) {  // weights of step = cc*9 + tap: K offset (tap*CIN + cc*64)
     const int cc = step / 9, tap = step - cc * 9;
     const int kofs_bytes = (tap * CIN + cc * 64) * 2;
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_b + (w_off[i] + kofs_bytes)),
-                                       (lptr_t)(Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+      buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
     });
   };
 
