@@ -997,17 +997,24 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     tile_origin(tile, b, py0, px0);
     const int R0 = 2 * (2 * py0 - 1), C0 = 2 * (2 * px0 - 1);
     if constexpr (U8IN) {
-      // raw bytes of image rows R0-3 .. , columns C0-3 .. C0+32, as aligned dwords
+      // raw bytes of image rows R0-3 .. , columns C0-3 .. C0+32, as aligned dwords.  The byte offset of
+      // window row `row` is tile_base + row * 672 with ONE 64-bit scalar per tile; its misalignment
+      // sh = offset & 3 is the same for every row and image (a row is 672 = 0 mod 4 bytes), so the
+      // per-lane part is 32-bit arithmetic only
       const unsigned char* src = reinterpret_cast<const unsigned char*>(xin_);
+      const int sh = ((C0 - 3) * 3) & 3;
+      const long long tile_base = (((long long)b * kPatch + (R0 - 3)) * kPatch + (C0 - 3)) * 3 - sh;
+      const long long lo = -tile_base, hi = in_bytes - 4 - tile_base;  // valid range of the per-lane offset
+      const int lo32 = lo > 0 ? (lo < 0x7fffffff ? (int)lo : 0x7fffffff) : 0;
+      const int hi32 = hi < 0 ? -1 : (hi < 0x7fffffff ? (int)hi : 0x7fffffff);
       static_for<PFR>([&](auto I) {
         constexpr int k = decltype(I)::value;
         const int i = tid + 256 * k;
         const int row = i / RAWDW, j = i - row * RAWDW;
         const int y = R0 + row - 3;
-        const long long off0 = (((long long)b * kPatch + y) * kPatch + (C0 - 3)) * 3;
-        const long long off = off0 - (off0 & 3) + 4 * j;
-        const bool ok = i < NRAW && (unsigned)y < (unsigned)kPatch && off >= 0 && off + 4 <= in_bytes;
-        const unsigned v = *reinterpret_cast<const unsigned*>(src + (ok ? off : 0));
+        const int voff = row * (kPatch * 3) + 4 * j;
+        const bool ok = i < NRAW && (unsigned)y < (unsigned)kPatch && voff >= lo32 && voff <= hi32;
+        const unsigned v = *reinterpret_cast<const unsigned*>(src + tile_base + (ok ? voff : lo32));
         praw[k] = ok ? v : 0u;
       });
     } else {
@@ -1043,11 +1050,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     int b, py0, px0;
     tile_origin(tile, b, py0, px0);
     const int R0 = 2 * (2 * py0 - 1), C0 = 2 * (2 * px0 - 1);
+    const int sh = ((C0 - 3) * 3) & 3;  // misalignment of the window's first byte: the same for every row
     for (int i = tid; i < NPIECE; i += 256) {
       const int row = i / PPR, cp = i - row * PPR;
       const int y = R0 + row - 3;
-      const long long off0 = (((long long)b * kPatch + y) * kPatch + (C0 - 3)) * 3;
-      const int sh = (int)(off0 & 3);
       const unsigned char* rr = Rl + row * RAWROW + sh + 6 * cp;  // byte of channel 0 of the first pixel
       u32x4 v = {0u, 0u, 0u, 0u};
       if ((unsigned)y < (unsigned)kPatch) {
