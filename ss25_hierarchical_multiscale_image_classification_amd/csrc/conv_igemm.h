@@ -1120,16 +1120,21 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool inside = (sy0 + ly[i]) >= 0 && (sx0 + lx[i]) >= 0 && P[i] < NPX;
+      const unsigned inside_mask = inside ? 0xffffffffu : 0u;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           typename E::vec4 ov;
-          ov[0] = (T)(inside ? fmaxf(acc[i][j][4 * q + 0] + bv[j][q].x, 0.f) : 0.f);
-          ov[1] = (T)(inside ? fmaxf(acc[i][j][4 * q + 1] + bv[j][q].y, 0.f) : 0.f);
-          ov[2] = (T)(inside ? fmaxf(acc[i][j][4 * q + 2] + bv[j][q].z, 0.f) : 0.f);
-          ov[3] = (T)(inside ? fmaxf(acc[i][j][4 * q + 3] + bv[j][q].w, 0.f) : 0.f);
-          *reinterpret_cast<typename E::vec4*>(Sl + sidx[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = ov;
+          ov[0] = (T)fmaxf(acc[i][j][4 * q + 0] + bv[j][q].x, 0.f);
+          ov[1] = (T)fmaxf(acc[i][j][4 * q + 1] + bv[j][q].y, 0.f);
+          ov[2] = (T)fmaxf(acc[i][j][4 * q + 2] + bv[j][q].z, 0.f);
+          ov[3] = (T)fmaxf(acc[i][j][4 * q + 3] + bv[j][q].w, 0.f);
+          // out-of-image stem pixels become +0: one AND per packed dword instead of a select per value
+          u32x2 pk = __builtin_bit_cast(u32x2, ov);
+          pk[0] &= inside_mask;
+          pk[1] &= inside_mask;
+          *reinterpret_cast<u32x2*>(Sl + sidx[i] * SPX + (j * 32 + 8 * q + 4 * h) * 2) = pk;
         }
     }
     __syncthreads();  // stem tile complete; every wave is past its reads of patch[buf ^ 1]
