@@ -136,7 +136,7 @@ def run_resnet(args, rank, world, dev):
         u8 = data[i % pool]  # uint8[B,224,224,3] in HBM; ToTensor/Normalize is fused into the stem kernel
         f, l, lab = net.forward(u8, want_feats=True, want_logits=True, want_labels=True)
         if world > 1:
-            l, lab = hdist.all_gather_rows(l), hdist.all_gather_rows(lab)
+            l, lab = hdist.all_gather_equal(l), hdist.all_gather_equal(lab)  # equal shards: no count exchange
         return f, l, lab
 
     for i in range(args.warmup):

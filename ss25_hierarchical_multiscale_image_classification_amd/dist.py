@@ -78,6 +78,19 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def all_gather_equal(t: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather along dim 0 when every rank holds the SAME number of rows (the benchmark's equal patch
+    shards): one collective into one preallocated tensor, no count exchange, no host synchronisation."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return all_gather_equal(t.cpu(), group).to(t.device)
+    world = dist.get_world_size(group)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
 def gather_results(feats: torch.Tensor, logits: Optional[torch.Tensor], meta: torch.Tensor, group=None):
     """Collect every rank's per-patch rows on every rank (rank-major order)."""
     return (all_gather_rows(feats, group), all_gather_rows(logits, group) if logits is not None else None,

@@ -106,3 +106,18 @@ def test_global_batch_nt_xent_matches_single_process():
         # each rank computed the full loss, so summing over ranks' identical losses scales grads by world
         assert np.allclose(gi, zi.grad[sl].numpy() * world, atol=1e-5)
         assert np.allclose(gj, zj.grad[sl].numpy() * world, atol=1e-5)
+
+
+def _equal_job(rank, world):
+    l = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank
+    lab = torch.arange(3, dtype=torch.int64) + 10 * rank
+    return hdist.all_gather_equal(l).numpy(), hdist.all_gather_equal(lab).numpy()
+
+
+def test_equal_shard_gather_is_rank_major():
+    # the benchmark's collective (equal patch shards per rank): one all_gather_into_tensor, no count exchange
+    outs = _run(2, _equal_job)
+    exp_l = np.concatenate([np.arange(6, dtype=np.float32).reshape(3, 2) + 100 * r for r in range(2)])
+    exp_lab = np.concatenate([np.arange(3) + 10 * r for r in range(2)])
+    for l, lab in outs:
+        assert np.array_equal(l, exp_l) and np.array_equal(lab, exp_lab)
