@@ -43,11 +43,13 @@ def _conv_macs(cin, cout, k, ho):
 
 OPS = [("stem7x7+pool", _conv_macs(3, 64, 7, 112)), ("(fused)", 0)]
 for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14), (256, 512, 7))):
-    if _s > 0:  # the 1x1/2 projection shortcut rides inside the 3x3/2 launch; its op slot stays empty
+    if _s in (1, 2):  # layers 2-3: the 1x1/2 projection shortcut rides inside the 3x3/2 launch (empty op slot)
         OPS.append((f"l{_s+1}b0c1+proj", _conv_macs(_ci, _co, 3, _ho) + _conv_macs(_ci, _co, 1, _ho)))
         OPS.append(("(fused)", 0))
     else:
         OPS.append((f"l{_s+1}b0c1", _conv_macs(_ci, _co, 3, _ho)))
+        if _s == 3:       # layer4 keeps a separate projection launch
+            OPS.append(("l4proj", _conv_macs(_ci, _co, 1, _ho)))
     OPS.append((f"l{_s+1}b0c2", _conv_macs(_co, _co, 3, _ho)))
     OPS.append((f"l{_s+1}b1c1", _conv_macs(_co, _co, 3, _ho)))
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
