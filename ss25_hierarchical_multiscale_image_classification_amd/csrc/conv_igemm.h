@@ -253,7 +253,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // second epilogue (bias only, no ReLU) into `outp_p`: one launch, one pass over the input.
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
           bool RELU, bool RESID, bool OUTF32, bool PROJ = false>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void conv_glds_kernel(
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kernel(
     const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
     const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page,
     const T* __restrict__ wgt_p = nullptr, const float* __restrict__ bias_p = nullptr,
@@ -1732,6 +1732,9 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
 #ifndef HIPAC_FUSE_PROJ
 #define HIPAC_FUSE_PROJ 1
 #endif
+#ifndef HIPAC_FUSE_PROJ_MAXCO
+#define HIPAC_FUSE_PROJ_MAXCO 256  // layer4 (512): 181 ns fused at 251 VGPRs vs 118 + 36 separate
+#endif
 
 // 3x3 / stride 2 conv (+BN+ReLU) of a down-sampling BasicBlock with its 1x1 / stride 2 projection
 // shortcut (+BN) riding along (conv_glds_kernel<..., PROJ = true>): x -> (out, out_p)
@@ -1797,7 +1800,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   const char* z = net.zero_page;
   // block 0
   const void* idt = x;
-  if constexpr (STRIDE == 2 && sizeof(T) == 2 && HIPAC_FUSE_PROJ && CO <= 256) {
+  if constexpr (STRIDE == 2 && sizeof(T) == 2 && HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
     // one launch: conv1 and the projection shortcut (the op slot of the projection stays empty).
     // Not for layer4: its second accumulator set pushes the kernel past 256 registers, i.e. to
     // one workgroup per CU (measured 349 ns/img fused vs 132 + 37 separate).
