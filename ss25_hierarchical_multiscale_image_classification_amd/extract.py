@@ -345,8 +345,10 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     carry = n_small % FWD if n_small else 0
     buf_s, mk_s = None, []
     if n_small:
+        # allocated on the caller's stream and released only after `main.wait_stream(side)` below has been
+        # enqueued: no record_stream (it would make the caching allocator hold the block until the side
+        # stream drains and cudaMalloc a fresh multi-GB buffer for every pipelined call)
         buf_s = torch.empty((n_small, 224, 224, 3), dtype=torch.uint8, device=dev)
-        buf_s.record_stream(side)
         with torch.cuda.stream(side):
             done = 0
             for lw, k in zip(lws, kepts):
@@ -359,7 +361,6 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     proc_meta[big] = (lwb.meta(kb), nb)
     if carry + nb:
         buf_b = torch.empty((carry + nb, 224, 224, 3), dtype=torch.uint8, device=dev)
-        buf_b.record_stream(side)
         mk_b = []
         with torch.cuda.stream(side):
             if carry:
