@@ -1335,16 +1335,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
     // MFMAs of step s, so an LDS read has PF MFMA pairs (PF x 64 cycles) to return
     constexpr int PF = HIPAC_C64_PF;
     frag ring[PF + 1][2];
+    // address of fragment (tap, kk, i) = lane base + compile-time slot offset + swizzled chunk, with the
+    // chunk term factored per axis: bit 4 = ((hx >> 1) & 1) ^ h depends on kw only, bits 5-6 =
+    // (hy & 3) ^ kk on kh only (hy & 3 does not depend on i) -- 2 VALU per k16 step instead of ~5 per read
+    int ax[3], by[3];
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      ax[k3] = ((((lx + k3) >> 1) & 1) ^ h) << 4;
+      by[k3] = ((ly0 + k3) & 3) << 5;
+    }
+    const unsigned char* const Hb = Hl + ((ly0 * HALO + lx) << 7);
     auto rd_step = [&](auto S) {
       constexpr int st = decltype(S)::value;
       constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
+      const unsigned char* const ptr = Hb + (ax[kw] | (by[kh] ^ (kk << 5)));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int hy = 4 * i + ly0 + kh, hx = lx + kw;
-        const int sw = ((hx >> 1) & 1) | ((hy & 3) << 1);
-        const int abase = ((hy * HALO + hx) << 7) | ((sw ^ h) << 4);  // chunk (2kk+h) ^ sw = (2kk) ^ (h ^ sw)
-        ring[st % (PF + 1)][i] = *reinterpret_cast<const frag*>(Hl + (abase ^ (kk << 5)));
-      }
+      for (int i = 0; i < 2; ++i)
+        ring[st % (PF + 1)][i] = *reinterpret_cast<const frag*>(ptr + (((4 * i + kh) * HALO + kw) << 7));
     };
     static_for<PF>([&](auto S) { rd_step(S); });
     static_for<36>([&](auto S) {
@@ -1544,12 +1551,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_kernel(const T* __restri
     __builtin_amdgcn_s_setprio(1);
     constexpr int PF = 2;
     frag ring[PF + 1];
+    // fragment address = lane base + compile-time slot offset + swizzled chunk, the chunk term factored per
+    // axis: bit 4 = ((pcol >> 1) & 1) ^ h depends on kw only, bits 5-6 = ((hy >> 1) & 3) ^ kk on kh only
+    int ax[3], by[3];
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const int pcol = (k3 & 1) * 8 + lx + (k3 >> 1);
+      ax[k3] = (((pcol >> 1) & 1) ^ h) << 4;
+      by[k3] = (((2 * ly + k3) >> 1) & 3) << 5;
+    }
+    const unsigned char* const Hb = Hl + (((2 * ly) << 4) + lx) * 128;
     auto rd_step = [&](auto S) {
       constexpr int st = decltype(S)::value;
       constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
-      const int hy = 2 * ly + kh, pcol = (kw & 1) * 8 + lx + (kw >> 1);
-      const int key = ((pcol >> 1) & 1) | (((hy >> 1) & 3) << 1);
-      ring[st % (PF + 1)] = *reinterpret_cast<const frag*>(Hl + (((hy << 4) + pcol) << 7) + (((2 * kk + h) ^ key) << 4));
+      ring[st % (PF + 1)] = *reinterpret_cast<const frag*>(Hb + (ax[kw] | (by[kh] ^ (kk << 5))) +
+                                                           (((kh << 4) + (kw & 1) * 8 + (kw >> 1)) << 7));
     };
     static_for<PF>([&](auto S) { rd_step(S); });
     static_for<36>([&](auto S) {
