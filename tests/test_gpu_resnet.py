@@ -265,9 +265,14 @@ def test_large_ragged_batches_two_lanes_default_schedule(n):
     assert torch.equal(lab, torch.cat([p[2] for p in pieces]))
 
 
-def test_forward_is_hip_graph_capturable():
+@pytest.mark.parametrize("two_lanes", [False, True])
+def test_forward_is_hip_graph_capturable(monkeypatch, two_lanes):
     # the library only enqueues work on the caller's stream (plus its fork/join lane): a forward can be
-    # captured into a HIP graph and replayed; results equal the eager launch bit for bit
+    # captured into a HIP graph and replayed; results equal the eager launch bit for bit -- also when the
+    # batch is split over the two launch lanes (event fork/join inside the capture)
+    if two_lanes:
+        monkeypatch.setenv("HIPAC_SUBBATCH", "8")
+        monkeypatch.setenv("HIPAC_GROUP", "16")
     sd = synth.seeded_resnet18_state_dict(1, num_classes=2)
     net = capi.PackedResNet18(sd, precision="bf16")
     u8 = synth.synth_patches_u8(40, seed=2, device="cuda")
