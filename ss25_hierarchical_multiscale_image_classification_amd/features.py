@@ -71,6 +71,26 @@ def save_feature_files(level: int, feats, labels, paths, out_dir: str = "."):
             f.write(f"{p}\n")
 
 
+def save_froc_csv(path: str, logits, meta, level_downsamples, tumor_class: int = 1) -> int:
+    """Per-slide detection list in the format ``readCSVContent`` parses
+    (src/utils/evaluation_FROC.py:67-88): one line ``probability,x,y`` per scored window with
+    float probability and INTEGER level-0 coordinates (the evaluation indexes its mask with
+    ``int(x / 2**level)``, :131-132).  ``logits`` [n,C] and ``meta`` int32[n,4] = (level, x, y, label)
+    as returned by ``extract.score_slide``; the detection point is the window centre.  Returns the
+    number of lines written."""
+    from .extract import PATCH_SIZES
+
+    lg = torch.as_tensor(logits).float().cpu()
+    m = torch.as_tensor(meta).cpu().numpy()
+    prob = torch.softmax(lg, dim=1)[:, tumor_class].numpy() if lg.numel() else np.zeros((0,), np.float32)
+    with open(path, "w") as f:
+        for p_, (lvl, x, y, _) in zip(prob, m):
+            ds = float(level_downsamples[int(lvl)])
+            half = PATCH_SIZES.get(int(lvl), 224) / 2.0
+            f.write(f"{float(p_):.6f},{int((x + half) * ds)},{int((y + half) * ds)}\n")
+    return len(m)
+
+
 @torch.no_grad()
 def extract_features_from_slide(slide: DeviceSlide, net: capi.PackedResNet18, level: int,
                                 stride: Optional[int] = None, batch_windows: int = 512):

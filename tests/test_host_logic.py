@@ -131,3 +131,22 @@ def test_cli_surface_keeps_reference_flags():
     with pytest.raises(SystemExit):
         p.parse_args(["--strategy", "nope"])
     assert main(["--download"]) == 2  # out-of-scope reference flag: refused with a message
+
+
+def test_froc_csv_is_what_the_reference_reader_parses(tmp_path):
+    # src/utils/evaluation_FROC.py:67-88 reads `float(prob), int(x), int(y)` per line; coordinates are level-0
+    import torch
+    from ss25_hierarchical_multiscale_image_classification_amd import features
+
+    logits = torch.tensor([[2.0, 0.0], [0.0, 2.0], [0.5, 0.5]])
+    meta = torch.tensor([[0, 0, 0, 0], [1, 224, 448, 1], [3, 0, 224, 0]], dtype=torch.int32)
+    path = tmp_path / "slide_001.csv"
+    n = features.save_froc_csv(str(path), logits, meta, level_downsamples=(1.0, 2.0, 4.0, 8.0))
+    assert n == 3
+    probs, xs, ys = [], [], []
+    for line in open(path).readlines():  # the reference's parse, restated
+        e = line.rstrip().split(",")
+        probs.append(float(e[0])), xs.append(int(e[1])), ys.append(int(e[2]))
+    assert abs(probs[0] - 0.119203) < 1e-5 and abs(probs[1] - 0.880797) < 1e-5 and abs(probs[2] - 0.5) < 1e-6
+    # window centres in level-0 pixels: level 0 window 1792 -> (896, 896); level 1 (224,448)+448 -> x2; level 3 +112 -> x8
+    assert (xs, ys) == ([896, (224 + 448) * 2, 112 * 8], [896, (448 + 448) * 2, (224 + 112) * 8])
