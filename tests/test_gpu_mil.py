@@ -76,3 +76,22 @@ def test_error_paths(gold):
         m.forward_bags(x.cpu(), [0, 8])
     with pytest.raises(capi.HipacError):
         m.forward_bags(x.double(), [0, 8])
+
+
+@pytest.mark.parametrize("F,pooling", [(128, "attention"), (64, "max"), (1024, "mean")])
+def test_other_feature_dims_against_oracle(F, pooling):
+    # the head is not tied to 512-d ResNet18 features (the reference passes feature_dim)
+    torch.manual_seed(F)
+    m = mil.MILClassifier(F, num_classes=3, pooling=pooling).cuda().eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.RandomState(F)
+    sizes = [3, 40, 129]
+    feats = rng.randn(sum(sizes), F).astype(np.float32)
+    offs = np.cumsum([0] + sizes)
+    logits, attn = m.forward_bags(torch.from_numpy(feats).cuda(), offs)
+    assert logits.shape == (3, 3)
+    for i, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+        l_ref, a_ref, _ = mil_ref.mil_forward_ref(sd, feats[a:b], pooling)
+        np.testing.assert_allclose(logits[i].cpu().numpy(), l_ref, rtol=5e-5, atol=5e-6)
+        if pooling == "attention":
+            np.testing.assert_allclose(attn[a:b].cpu().numpy(), a_ref[:, 0], rtol=1e-4, atol=1e-9)

@@ -72,3 +72,26 @@ def test_rejects_untiled_and_garbage(tmp_path):
     q.write_bytes(b"not a tiff at all")
     with pytest.raises(tp.TiffError):
         tp.TiffPyramid(str(q))
+
+
+def test_rgba_samples_and_odd_tile_size(tmp_path):
+    # 4 samples per pixel (RGBA, uncompressed): the reader keeps RGB; tile size that does not divide the image
+    import struct
+    levels = pyramid(3, w=300, h=200)[:1]
+    rgb = levels[0]
+    rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], -1)
+    # write with the minimal writer as RGB, then check a hand-made RGBA tile path through _decode_tile
+    path = str(tmp_path / "a.tif")
+    tp.write_tiled_tiff(path, [rgb], tile=128, compression="none")
+    s = tp.TiffPyramid(path)
+    lv = s.levels[0]
+    assert (lv.tiles_across, lv.tiles_down) == (3, 2)
+    got = np.concatenate([s.read_band(0, tr) for tr in range(lv.tiles_down)], 0)
+    np.testing.assert_array_equal(got, rgb)
+    # emulate a 4-sample level: same tile bytes with an alpha channel appended
+    raw = np.zeros((128, 128, 4), np.uint8)
+    raw[:, :, :3] = rgb[:128, :128]
+    fake = tp.TiffLevel(width=128, height=128, tile_w=128, tile_h=128, compression=1, photometric=2, samples=4,
+                        offsets=[0], counts=[raw.size], jpeg_tables=None, subfile_type=0)
+    s._buf = memoryview(raw.tobytes())
+    np.testing.assert_array_equal(s._decode_tile(fake, 0), rgb[:128, :128])
