@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet|wsi]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet|wsi|simclr]
 
-Default workload (BASELINE.json configs[1]): batched ResNet18 bf16 inference over
-synthetic 224x224 patches that are already resident in HBM as uint8 HWC.  One STEP =
-one pass of the hot path over one batch of 8192 patches: ToTensor/Normalize (fused into
-the stem kernel) + the MFMA ResNet18 forward producing features [B,512],
-logits [B,2] and argmax labels.  8 steps = the 64k patches of the config.  With N > 1
-every rank scores its own patches (slides shard, no data-path collective) and the
-per-patch logits/labels are all-gathered over RCCL once per step (weak scaling).
+One command covers BASELINE.json's whole metric.  Default workload (configs[1]): batched ResNet18 bf16
+inference over synthetic 224x224 patches already resident in HBM as uint8 HWC; one STEP = one pass of the hot
+path over one batch of 8192 patches (ToTensor/Normalize folded into the stem kernel + the MFMA ResNet18
+forward -> features [B,512], logits [B,2], argmax labels); 8 steps = the 64k patches of the config.  The same
+JSON line also carries
+  "wsi"          -- configs[2] and north_star's 100k slide: whole-slide hierarchical scan (levels 0-3, reference
+                    grid), s/slide, kept patches/s, the level-0 resampler's HBM roofline, CPU extractor baseline
+  "parity"       -- max norm-relative error of features / logits and label mismatches of every precision against
+                    the fp32 oracle on the first 256 patches of the workload (configs[0]), outside the timed region
+  "roofline"     -- dominant kernel: algorithmic FLOPs per launch / average launch duration (HIP events, launch stream)
+  "cpu_baseline" -- configs[0]: the oracle on the host cores, batch 256 (and 512), warm-up + timed iterations, median
+`--workload wsi` makes the whole-slide scan the timed step (with --gpus N: configs[3], one slide per rank and
+one ragged all-gather of features + logits + meta); `--workload simclr` times the native SimCLR training step
+(configs[4]).
 
-Prints ONE JSON line (rank 0) with the driver's fields plus
-  "roofline"     -- dominant kernel: algorithmic FLOPs per launch / its average launch
-                    duration measured here with HIP events on the launch stream
-  "cpu_baseline" -- the oracle (torch fp32 functional ResNet18 on the host cores) timed
-                    on a bounded sample of the same workload (rank 0, N = 1 only)
+--gpus N > 1: when not already under torch.distributed.run (no WORLD_SIZE in the environment) this process
+only LAUNCHES: it starts N fresh child processes, one rank per GPU (RCCL), before anything touches the GPU,
+relays rank 0's JSON line and exits non-zero if a child fails.  Every rank scores its own units (slides /
+patch shards: no data-path collective), results are all-gathered once per step (weak scaling).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +42,9 @@ from ss25_hierarchical_multiscale_image_classification_amd import capi, dist as 
 
 FLOP_PER_PATCH = 2 * 1_813_562_368  # convs + fc, BN folded
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
+PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+
 
 # trunk ops (hipac_resnet18_run_ops): name, MACs per image
 def _conv_macs(cin, cout, k, ho):
@@ -54,6 +64,27 @@ for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14
     OPS.append((f"l{_s+1}b1c1", _conv_macs(_co, _co, 3, _ho)))
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
 assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
+
+KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip_kernel", "l1": "conv3x3_c64_kernel", "l2b0c1+proj": "conv3x3s2_c64_kernel",
+                "l3b0c1+proj": "conv_glds_kernel", "l4b0c1": "conv_glds_kernel", "l4proj": "conv_glds_kernel"}
+
+
+def kernel_of(op: str) -> str:
+    return KERNEL_OF_OP.get(op) or KERNEL_OF_OP.get(op[:2]) or "conv3x3_halo_kernel"
+
+
+def host_threads() -> int:
+    """CPU threads this process may really use: the smaller of the affinity mask and the cgroup CPU quota
+    (a GPU box hands one GPU's share of a big host: os.cpu_count() there is the HOST's core count and
+    running torch on that many threads oversubscribes the share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def per_op_times(net: capi.PackedResNet18, dev, reps: int = 20):
@@ -84,25 +115,63 @@ def per_op_times(net: capi.PackedResNet18, dev, reps: int = 20):
     return out
 
 
-def cpu_baseline(n_sample: int = 256):
-    """Oracle ResNet18 forward on the host cores (config 1: 256 random patches, fp32)."""
+def cpu_baseline(u8_256: torch.Tensor, budget_s: float = 45.0):
+    """BASELINE configs[0] as SURVEY.md 8(d) states it: the oracle (torch fp32 functional ResNet18) on the host
+    cores, batch 256 (then 512), 3 warm-up + up to 10 timed iterations, median, threads stated.  Bounded: the
+    timed loops stop once `budget_s` of CPU work is spent (the iteration counts actually run are reported).
+    Also returns the oracle's outputs on the 256 patches (the parity reference)."""
     from oracle import resnet18_ref, transform_ref  # the checker, timed as the reported baseline only
 
+    threads = host_threads()
+    torch.set_num_threads(threads)
     sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
-    u8 = synth.synth_patches_u8(n_sample, seed=1)
     lut = torch.from_numpy(transform_ref.normalize_lut())
-    x = torch.stack([lut[c][u8[..., c].long()] for c in range(3)], dim=1)  # [n,3,224,224] fp32
-    threads = torch.get_num_threads()
-    resnet18_ref.resnet18_forward(x[:32], sd)  # warm-up
-    t0 = time.time()
-    done = 0
-    while done < n_sample:
-        resnet18_ref.resnet18_forward(x[done : done + 64], sd)
-        done += 64
-    dt = time.time() - t0
-    return {"value": n_sample / dt, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"{n_sample} random 224x224x3 patches, fp32 torch-functional ResNet18 (oracle), batch 64, "
-                      f"{dt:.1f} s of CPU work"}
+    x = torch.stack([lut[c][u8_256[..., c].long()] for c in range(3)], dim=1)  # [256,3,224,224] fp32
+    t_start = time.time()
+    ref = resnet18_ref.resnet18_forward(x, sd)  # warm-up 1 (and the parity reference)
+    runs = {}
+    for batch, warm, timed in ((256, 2, 10), (512, 1, 5)):
+        xb = x if batch == 256 else torch.cat([x, x])
+        for _ in range(warm):
+            resnet18_ref.resnet18_forward(xb, sd)
+        ts = []
+        for _ in range(timed):
+            t0 = time.time()
+            resnet18_ref.resnet18_forward(xb, sd)
+            ts.append(time.time() - t0)
+            if time.time() - t_start > budget_s and len(ts) >= 3:
+                break
+        ts.sort()
+        runs[batch] = {"patches_per_s": batch / ts[len(ts) // 2], "timed_iterations": len(ts), "warmup": warm + (batch == 256)}
+        if time.time() - t_start > budget_s:
+            break
+    dt = time.time() - t_start
+    rec = {"value": runs[256]["patches_per_s"], "unit": "patches/s", "cores": threads, "kind": "port",
+           "sample": f"configs[0]: 256 random 224x224x3 patches, fp32 torch-functional ResNet18 (oracle), batch 256, "
+                     f"{runs[256]['warmup']} warm-up + {runs[256]['timed_iterations']} timed iterations, median; "
+                     f"{dt:.1f} s of CPU work in all", "batches": runs, "host_cpu_count": os.cpu_count()}
+    return rec, ref
+
+
+def parity_block(nets: dict, u8_256_dev: torch.Tensor, ref):
+    """Per precision: max norm-relative error (max|a-b| / max|b|) of features and logits against the fp32 oracle
+    on the 256 patches of configs[0], label mismatches, and how many of those sit on oracle near-ties."""
+    ref_f, ref_l = ref
+    ref_lab = ref_l.argmax(1)
+    margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
+    out = {"patches": int(u8_256_dev.shape[0]), "reference": "oracle/resnet18_ref.py (torch fp32, CPU)",
+           "metric": "max|a-b| / max|b| per tensor"}
+    for name, net in nets.items():
+        f, l, lab = net.forward(u8_256_dev, want_feats=True, want_logits=True, want_labels=True)
+        f, l, lab = f.cpu(), l.cpu(), lab.cpu()
+        ef = float((f - ref_f).abs().max() / ref_f.abs().max())
+        el = float((l - ref_l).abs().max() / ref_l.abs().max())
+        bad = lab != ref_lab
+        bound = 2 * float((l - ref_l).abs().max())
+        out[name] = {"features": ef, "logits": el, "label_mismatches": int(bad.sum()),
+                     "label_mismatches_outside_near_ties": int((bad & (margin > bound)).sum()),
+                     "meets_1e-3": bool(ef <= 1e-3 and el <= 1e-3)}
+    return out
 
 
 def cpu_baseline_wsi(side: int = 4000):
@@ -126,6 +195,94 @@ def cpu_baseline_wsi(side: int = 4000):
                       f"extractor + Pillow resize + normalise only (no ResNet), {dt:.1f} s of CPU work"}
 
 
+def _max_over_ranks(dt: float, world: int, dev) -> float:
+    if world == 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def planes_roofline(slide, side):
+    """The HBM-bound kernel of the slide scan: the level-0 resampler (hipac_level_build_planes).  Algorithmic bytes
+    = every level-0 source byte once (unique bytes); HIP events on the launch stream."""
+    w0, h0 = slide.level_dimensions[0]
+    capi.LevelPlanes(slide.levels[0], 1792, width=w0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        capi.LevelPlanes(slide.levels[0], 1792, width=w0)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    gbs = w0 * h0 * 3 / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath) and side == 50000:  # the PMC passes were taken on the default 50 000^2 slide
+        traffic = json.load(open(tpath)).get("wsi_level0_planes")
+    return {"bound": "hbm", "kernel": "hipac_level_build_planes[level 0]", "achieved": gbs, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "launch_ms": ms,
+            "bytes_per_launch": w0 * h0 * 3}
+
+
+def scan_slide_timed(net, slide, args, world, steps, warmup, dev):
+    """Time `steps` whole-slide scans (levels 0-3).  Returns (seconds per slide, windows, kept)."""
+    from ss25_hierarchical_multiscale_image_classification_amd import extract
+
+    stride_of = (lambda lvl: None) if args.grid == "reference" else (lambda lvl: extract.PATCH_SIZES[lvl])
+    n_all = 0
+    for lvl in (0, 1, 2, 3):
+        w, h = slide.level_dimensions[lvl]
+        n_all += len(extract.window_grid(w, h, lvl, stride_of(lvl))[2])
+
+    def step():
+        f, l, p, meta = extract.score_slide(slide, net, levels=(0, 1, 2, 3), batch_windows=args.batch_windows,
+                                            stride=stride_of)
+        if world > 1:  # configs[3]: the one exchange of the path -- ragged all-gather, rank-major order
+            f, l, meta = hdist.gather_results(f, l, meta)
+        return f.shape[0]
+
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n_kept = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
+    return dt / steps, n_all, n_kept
+
+
+def wsi_object(net, args, rank, world, dev, sides):
+    """The whole-WSI half of the metric inside the default line: per slide side a record of the scan."""
+    from ss25_hierarchical_multiscale_image_classification_amd import extract
+
+    out = {"levels": "0-3", "grid": args.grid, "dtype": "u8+" + args.precision,
+           "step": "one whole synthetic slide per rank: window decisions + Pillow-exact resize + ResNet18"}
+    for side in sides:
+        key = f"{side}x{side}"
+        try:
+            slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
+            s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, steps=2 if side <= 50000 else 1, warmup=1, dev=dev)
+            rec = {"s_per_slide": s_per, "windows": n_all, "kept": n_kept, "n_gpus": world,
+                   "kept_patches_per_s": world * n_kept / s_per if world == 1 else None,
+                   "unique_source_GBps": world * sum(w * h * 3 for (w, h) in slide.level_dimensions) / s_per / 1e9}
+            if rank == 0:
+                rec["roofline"] = planes_roofline(slide, side)
+            out[key] = rec
+            del slide
+            torch.cuda.empty_cache()
+        except (RuntimeError, capi.HipacError) as e:  # e.g. out of memory on a smaller card: report, do not die
+            out[key] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
+    return out
+
+
 def run_resnet(args, rank, world, dev):
     B = args.batch
     sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
@@ -135,7 +292,7 @@ def run_resnet(args, rank, world, dev):
     data = [synth.synth_patches_u8(B, seed=1 + rank * 1000 + i, device=dev) for i in range(pool)]
 
     def step(i):
-        u8 = data[i % pool]  # uint8[B,224,224,3] in HBM; ToTensor/Normalize is fused into the stem kernel
+        u8 = data[i % pool]  # uint8[B,224,224,3] in HBM; ToTensor/Normalize is folded into the stem kernel
         f, l, lab = net.forward(u8, want_feats=True, want_logits=True, want_labels=True)
         if world > 1:
             l, lab = hdist.all_gather_equal(l), hdist.all_gather_equal(lab)  # equal shards: no count exchange
@@ -152,11 +309,7 @@ def run_resnet(args, rank, world, dev):
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
     assert out[1].shape[0] == B * world
     value = world * B * args.steps / dt
     rec = {
@@ -168,6 +321,7 @@ def run_resnet(args, rank, world, dev):
                    "outputs": "features[B,512] + logits[B,2] + labels", "weights": "seeded random init",
                    "parallelism": f"patch shards x{world}, all-gather of logits/labels" if world > 1 else "single GPU"},
         "tflops_whole_path": value * FLOP_PER_PATCH / 1e12 / world,
+        "frac_of_peak_whole_path": value * FLOP_PER_PATCH / 1e12 / world / PEAK_BF16_DENSE_TFLOPS,
     }
     if rank == 0:
         ops = per_op_times(net, dev)
@@ -177,20 +331,22 @@ def run_resnet(args, rank, world, dev):
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["op"])
-        kname = {"stem7x7+pool": "stem_pool_kernel", "l1": "conv3x3_c64_kernel"}.get(
-            dom["op"] if dom["op"].startswith("stem") else dom["op"][:2], "conv3x3_halo_kernel / conv_glds_kernel")
-        rec["roofline"] = {"bound": "mfma", "kernel": f"{kname}[{dom['op']}]", "achieved": dom["tflops"],
+        rec["roofline"] = {"bound": "mfma", "kernel": f"{kernel_of(dom['op'])}[{dom['op']}]", "achieved": dom["tflops"],
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_DENSE_TFLOPS,
                            "traffic": traffic, "launch_ms": dom["ms"], "flops_per_launch": dom["flops_per_launch"],
                            "images_per_launch": dom["images"]}
-        rec["per_op"] = [{"op": o["op"], "images": o["images"], "ms": round(o["ms"], 4),
-                          "tflops": None if o["tflops"] is None else round(o["tflops"], 1)} for o in ops]
+        rec["per_op"] = [{"op": o["op"], "kernel": kernel_of(o["op"]) if o["tflops"] else None, "images": o["images"],
+                          "ms": round(o["ms"], 4), "tflops": None if o["tflops"] is None else round(o["tflops"], 1),
+                          "frac": None if o["tflops"] is None else round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3)} for o in ops]
         if traffic is not None:
             rec["roofline"]["traffic_source"] = "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        if world == 1 and args.precision == "bf16":
-            # same inputs, same kernels instantiated for fp16 operands: the precision that meets the
-            # north star's 1e-3 relative tolerance (tests/test_gpu_resnet.py) at the same rate
-            alt = capi.PackedResNet18(sd, precision="fp16")
+    nets = {args.precision: net}
+    if rank == 0 and world == 1:
+        # the same kernels instantiated for the other operand type, and the exact f32 MFMA parity mode
+        for alt_name in ("fp16", "bf16"):
+            if alt_name == args.precision:
+                continue
+            alt = capi.PackedResNet18(sd, precision=alt_name)
             for i in range(max(1, args.warmup)):
                 alt.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
             torch.cuda.synchronize()
@@ -198,12 +354,36 @@ def run_resnet(args, rank, world, dev):
             for i in range(args.steps):
                 alt.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
             torch.cuda.synchronize()
-            rec["alt_precision"] = {"dtype": "fp16", "value": B * args.steps / (time.perf_counter() - t0),
+            rec["alt_precision"] = {"dtype": alt_name, "value": B * args.steps / (time.perf_counter() - t0),
                                     "unit": "patches/s"}
-        if world == 1:
-            rec["pcie_inclusive"] = pcie_inclusive(net, data[0], steps=min(4, args.steps))
-        if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline()
+            nets[alt_name] = alt
+        net32 = capi.PackedResNet18(sd, precision="fp32")
+        n32 = min(B, 2048)
+        net32.forward(data[0][:n32].contiguous(), want_feats=True, want_logits=True, want_labels=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net32.forward(data[0][:n32].contiguous(), want_feats=True, want_logits=True, want_labels=True)
+        torch.cuda.synchronize()
+        v32 = n32 / (time.perf_counter() - t0)
+        rec["parity_mode"] = {"dtype": "fp32", "value": v32, "unit": "patches/s", "patches": n32,
+                              "tflops": v32 * FLOP_PER_PATCH / 1e12, "frac_of_f32_mfma_peak": v32 * FLOP_PER_PATCH / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        nets["fp32"] = net32
+        rec["pcie_inclusive"] = pcie_inclusive(net, data[0], steps=min(4, args.steps))
+        if not args.no_cpu_baseline:
+            u8_256 = data[0][:256].contiguous()
+            rec["cpu_baseline"], ref = cpu_baseline(u8_256.cpu())
+            rec["parity"] = parity_block(nets, u8_256, ref)
+    del data
+    torch.cuda.empty_cache()
+    if not args.no_wsi:
+        sides = [int(s) for s in args.wsi_sides.split(",") if s]
+        if world > 1:
+            sides = sides[:1]  # configs[3]: one 50k slide per rank, gathered
+        w = wsi_object(net, args, rank, world, dev, sides)
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                w["cpu_baseline"] = cpu_baseline_wsi()
+            rec["wsi"] = w
     return rec
 
 
@@ -244,94 +424,112 @@ def pcie_inclusive(net, u8_dev, steps):
 
 
 def run_wsi(args, rank, world, dev):
-    """BASELINE.json configs[2]: hierarchical scan of one synthetic level-0 slide across
-    levels 0-3 with on-GPU whiteness filter + resize; one STEP = one whole slide."""
+    """BASELINE.json configs[2] (N = 1) / configs[3] (N > 1): hierarchical scan of one synthetic level-0 slide per
+    rank across levels 0-3 with on-GPU whiteness filter + resize; one STEP = one whole slide per rank; with N > 1
+    features + logits + meta of every rank are all-gathered (rank-major order = DataParallel's gather order)."""
     from ss25_hierarchical_multiscale_image_classification_amd import extract
 
     side = args.slide_side
     net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision=args.precision)
     slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
-    stride_of = (lambda lvl: None) if args.grid == "reference" else (lambda lvl: extract.PATCH_SIZES[lvl])
-
-    def step():
-        f, l, p, meta = extract.score_slide(slide, net, levels=(0, 1, 2, 3), batch_windows=args.batch_windows,
-                                            stride=stride_of)
-        n_all = 0
-        for lvl in (0, 1, 2, 3):
-            w, h = slide.level_dimensions[lvl]
-            n_all += len(extract.window_grid(w, h, lvl, stride_of(lvl))[2])
-        if world > 1:
-            hdist.gather_results(f, l, meta)
-        return f.shape[0], n_all
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_kept, n_all = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, args.steps, args.warmup, dev)
     unique_bytes = sum(w * h * 3 for (w, h) in slide.level_dimensions)
     extra = {}
     if rank == 0:
-        # dominant HBM-bound kernel of this workload: the level-0 resampler (hpass + vpass).
-        # algorithmic bytes = every level-0 source byte once (SURVEY 8d: unique bytes)
-        w0, h0 = slide.level_dimensions[0]
-        capi.LevelPlanes(slide.levels[0], 1792, width=w0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(3):
-            capi.LevelPlanes(slide.levels[0], 1792, width=w0)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / 3
-        gbs = w0 * h0 * 3 / (ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath) and side == 50000:  # the PMC passes were taken on the default 50 000^2 slide
-            traffic = json.load(open(tpath)).get("wsi_level0_planes")
-        extra["roofline"] = {"bound": "hbm", "kernel": "hipac_level_build_planes[level 0: hpass_kernel<8> + vpass_kernel<8>]",
-                             "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                             "traffic": traffic, "launch_ms": ms, "bytes_per_launch": w0 * h0 * 3}
+        extra["roofline"] = planes_roofline(slide, side)
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline_wsi()
     return {**extra,
-        "metric": "whole-WSI wall-clock (levels 0-3)", "value": dt / args.steps, "unit": "s/slide", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
+        "metric": "whole-WSI wall-clock (levels 0-3)", "value": s_per, "unit": "s/slide", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": s_per * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8+" + args.precision, "data": "synthetic",
         "config": {"workload": f"wsi_scan_{side}x{side}_levels0-3_{args.grid}_grid", "windows": n_all,
-                   "kept": n_kept, "parallelism": f"one slide per rank x{world}"},
-        "windows_per_s": world * n_all * args.steps / dt, "kept_patches_per_s": world * n_kept * args.steps / dt,
-        "unique_source_GBps": world * unique_bytes * args.steps / dt / 1e9,
+                   "kept_rank0": n_kept, "parallelism": f"one slide per rank x{world}, ragged all-gather of features/logits/meta"
+                   if world > 1 else "single GPU"},
+        "slides_per_s": world / s_per, "windows_per_s": world * n_all / s_per,
+        "unique_source_GBps": world * unique_bytes / s_per / 1e9,
     }
 
 
-def main():
+def run_simclr(args, rank, world, dev):
+    """BASELINE.json configs[4]: the native SimCLR training step (src/models/simclr.py:85-96): two train-mode
+    encoder + projector forwards on augmented-pair batches, NT-Xent over the global batch, backward, Adam.
+    One STEP = 2 x (1024 / N) views per rank; gradients are all-reduced over RCCL."""
+    from ss25_hierarchical_multiscale_image_classification_amd import train_native
+
+    return train_native.bench_simclr_step(args, rank, world, dev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` from a bare shell
+# ---------------------------------------------------------------------------------------------------------
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_commands(argv, n: int, port: int, python: str = sys.executable, base_env=None):
+    """(argv, env) of every rank's process: the same command line plus --_child, torchrun's environment
+    variables, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    base_env = dict(os.environ if base_env is None else base_env)
+    cmds = []
+    for r in range(n):
+        env = dict(base_env)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL fails without it on this driver
+        cmds.append(([python, os.path.join(ROOT, "bench.py"), *[a for a in argv if a != "--_child"], "--_child"], env))
+    return cmds
+
+
+def launch_ranks(argv, n: int) -> int:
+    """Start one fresh process per rank BEFORE this process touches the GPU, relay rank 0's stdout, wait for
+    all; exit code = first non-zero child code."""
+    procs = []
+    for r, (cmd, env) in enumerate(child_commands(argv, n, _free_port())):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return bad[0]
+    return 0
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["resnet", "wsi"], default="resnet")
+    ap.add_argument("--workload", choices=["resnet", "wsi", "simclr"], default="resnet")
     ap.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
     ap.add_argument("--batch", type=int, default=8192, help="patches per step per GPU")
     ap.add_argument("--slide_side", type=int, default=50000)
+    ap.add_argument("--wsi_sides", default="50000,100000", help="slide sides of the `wsi` object of the default line")
+    ap.add_argument("--no_wsi", action="store_true", help="default workload: skip the `wsi` object")
     ap.add_argument("--grid", choices=["reference", "nonoverlap"], default="reference")
     ap.add_argument("--batch_windows", type=int, default=4096)
+    ap.add_argument("--simclr_views", type=int, default=1024, help="simclr: images per view per step, over all ranks")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--one_device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
-    args = ap.parse_args()
+    ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
+    return ap
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = build_parser().parse_args(argv)
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        # parent: nothing here may initialise the GPU (torch.cuda.is_available() would)
+        return launch_ranks(argv, args.gpus)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
@@ -339,15 +537,17 @@ def main():
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
     rank, world, local = hdist.init_from_env(args.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", 0 if args.one_device else local)
     torch.cuda.set_device(dev)
-    rec = run_resnet(args, rank, world, dev) if args.workload == "resnet" else run_wsi(args, rank, world, dev)
+    run = {"resnet": run_resnet, "wsi": run_wsi, "simclr": run_simclr}[args.workload]
+    rec = run(args, rank, world, dev)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

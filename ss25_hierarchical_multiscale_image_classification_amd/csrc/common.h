@@ -95,6 +95,8 @@ struct Net {
   int precision;
   int num_classes;
   ConvW stem;
+  ConvW stem_u8;      // strip kernel (uint8 input): T[64][192] in its own K order, normalisation folded in
+  float stem_pad[3];  // value of a pixel outside the image, per channel, in the strip kernel's input units
   ConvW block[8][2];
   ConvW down[3];
   float* fc_w;  // device float[num_classes][512]
@@ -112,6 +114,7 @@ struct Plan {
   int esz;        // bytes per activation element: 2 (bf16 / fp16) or 4 (fp32 parity mode)
   int u8_input;   // 1: the stem reads raw uint8 HWC patches (normalise fused); needs fuse_stem
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
+  int stem_strip; // uint8 input: 1 = strip kernel (default), 0 = tile kernel with the LDS table (first form)
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]
   size_t stem;    // T[bc,112,112,64]

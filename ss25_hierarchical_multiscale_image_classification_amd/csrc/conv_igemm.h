@@ -1169,6 +1169,270 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused stem, uint8 input, second form ("strip" kernel): the same 7x7/2 conv + BN + ReLU + 3x3/2
+// max-pool on raw uint8 HWC patches, restructured so that NOTHING but the MFMA loop is expensive:
+//   * ToTensor / Normalize are folded into the weights and the bias at pack time: the kernel
+//     multiplies x'' = v/128 - 1 (exact in bf16 and fp16) by w'' = w * 128 / (255 std_c) and the bias
+//     carries -sum(w'' mu''_c), mu''_c = (255 mean_c - 128)/128; pixels outside the image take the
+//     value mu''_c (rounded to T), i.e. the normalised 0 the reference pads with.  No table, no
+//     per-pixel rounding of the input.
+//   * K is packed as (channel plane c, row pair rp, column quad cq) = 3 x 4 x 2 fragments of 8
+//     = 192 (147 real), 12 k16 steps instead of 14.  In LDS a plane holds, per column, the two rows
+//     of a row pair in one dword, so the fragment of stem column sx (input columns 2sx-3+4cq ..+3,
+//     rows 2sy-3+2rp, +1) is 16 contiguous bytes at 8 * sx + const: two conflict-free ds_read_b64,
+//     no replication of the patch, offsets are immediates.
+//   * lane = stem COLUMN, MFMA sub-tile = stem ROW: the 3x3/2 max-pool is a v_max3 over three
+//     accumulator sets (rows) of the same lane and two lane shifts; the stem tile never goes to
+//     LDS.  A workgroup walks DOWN a strip of 28 pooled columns (half the image width; wave =
+//     (channel half, 14-column half)), 4 pooled rows = 8 stem rows per step, and carries the last stem
+//     row in registers into the next step, so no stem row is computed twice in y
+//     (MFMA efficiency = 28/32 columns x 147/192 of K).
+//   * input rows arrive by LDS-DMA (buffer_load ... lds, dword pieces, range-checked) one step
+//     ahead; the conversion reads them as aligned dwords and writes 16-byte pieces.
+// ---------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void buffer_load_lds4(rsrc_t rs, void* lds, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 4, voffset, soffset, 0, 0);
+}
+#else
+__device__ inline void buffer_load_lds4(rsrc_t, void*, int, int) {}
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+
+template <typename T> struct PackPair;  // two exactly representable floats -> one dword of two T (lo, hi)
+template <> struct PackPair<_Float16> {
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));  // exact inputs: the rounding mode is moot
+  }
+  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    f16x4 t;  // round-to-nearest-even, as every other store of T in this library
+    t[0] = (_Float16)lo;
+    t[1] = (_Float16)hi;
+    return __builtin_bit_cast(u32x2, t)[0];
+  }
+};
+template <> struct PackPair<__bf16> {
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+  }
+  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    bf16x4 t;
+    t[0] = (__bf16)lo;
+    t[1] = (__bf16)hi;
+    return __builtin_bit_cast(u32x2, t)[0];
+  }
+};
+
+constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_pool_strip_kernel(const unsigned char* __restrict__ x,
+                                                                 const T* __restrict__ wgt,
+                                                                 const float* __restrict__ bias, T* __restrict__ out,
+                                                                 int n_strips, int in_bytes, float pv0, float pv1,
+                                                                 float pv2) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int NRP = 11, PXW = 128;                  // row pairs per step, window columns
+  constexpr int PLANE = NRP * PXW * 4;                // bytes of one channel plane
+  constexpr int PATCH_BYTES = 3 * PLANE;              // 16 896
+  constexpr int RAW_PITCH = 528, RAW_ROWS = 22;       // 2 DMA pieces of 256 B per row + 16 B; row 21 = never written
+  constexpr int RAW_BYTES = RAW_ROWS * RAW_PITCH;
+  constexpr int NPIECE = 21 * 2;                      // DMA pieces (256 B) per step
+  constexpr int PPW = (NPIECE + 3) / 4;               // pieces per wave (11; waves 2, 3 have 10)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCH_BYTES + RAW_BYTES];
+  unsigned char* const Pl = smem;
+  unsigned char* const Rl = smem + PATCH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jt = wave & 1, st = wave >> 1;  // channel half, 14-column half of the strip
+  const int r = lane & 31, h = lane >> 5;
+
+  // this lane's rows of the packed weight matrix: channel 32 jt + r, k = 16 s + 8 h .. + 7, s = 0..11
+  frag wreg[12];
+  {
+    const char* wb = reinterpret_cast<const char*>(wgt) + (size_t)(jt * 32 + r) * (192 * 2) + 16 * h;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) wreg[s] = *reinterpret_cast<const frag*>(wb + s * 32);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(wreg[s]));  // the loads retire here, not inside the step loop
+  }
+  const rsrc_t in_rsrc = make_rsrc(x, in_bytes);
+
+  // DMA of the 21 input rows of step (strip, ys): window row w = input row 16 ys - 3 + w, window
+  // column 0 = input column 112 side - 5; the dword-aligned run starts one byte earlier (3 X0 - 1 is a
+  // multiple of 4 for both sides).  Rows outside the image and bytes outside the tensor read as zeros
+  // (descriptor range check); the conversion replaces whatever lies outside the image anyway.
+  auto issue_dma = [&](int strip, int ys) {
+    const int b = strip >> 1, side = strip & 1;
+    const int base = b * (kPatch * kPatch * 3) + (16 * ys - 3) * (kPatch * 3) + 3 * (112 * side - 5) - 1;
+    static_for<PPW>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const int p = wave + 4 * k;
+      if (p < NPIECE) {
+        const int row = p >> 1, half = p & 1;
+        const int iy = 16 * ys - 3 + row;
+        const bool ok = (unsigned)iy < (unsigned)kPatch;
+        const int off = base + row * (kPatch * 3) + (half * 64 + lane) * 4;
+        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH + half * 256, ok ? off : (int)0x80000000, 0);
+      }
+    });
+  };
+
+  // conversion task of this thread (threads 0..175): row pair cRp, 8-column group cxg
+  const int cRp = tid >> 4, cxg = tid & 15;
+  const unsigned char* const craw = Rl + (2 * cRp) * RAW_PITCH + cxg * 24;
+  unsigned char* const cdst = Pl + cRp * (PXW * 4) + cxg * 32;
+  const float pvc[3] = {pv0, pv1, pv2};
+
+  // fragment base of this lane: window column 2 r + 56 st (+ 4 for the second column quad)
+  const unsigned char* const fbase = Pl + (2 * r + 56 * st) * 4 + 16 * h;
+
+  f32x16 carry;  // raw accumulators of the last stem row of the previous step
+  const int n_steps = ((n_strips - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * kStripSteps;
+  if ((int)blockIdx.x < n_strips) issue_dma(blockIdx.x, 0);
+  for (int g = 0; g < n_steps; ++g) {
+    const int strip = blockIdx.x + (g / kStripSteps) * gridDim.x;
+    const int ys = g % kStripSteps;
+    const int b = strip >> 1, side = strip & 1;
+    // this wave's DMA pieces of the step have landed once only the 16 stores of the previous epilogue
+    // (issued later: vmcnt retires in order) are still outstanding
+    if (g == 0) wait_vmcnt<0>();
+    else wait_vmcnt<16>();
+    __builtin_amdgcn_s_barrier();  // this step's raw rows landed; every wave is past the previous MFMA loop
+#ifdef HIPAC_ABL_STRIP_NO_CONVERT
+    if (n_strips < 0)
+#endif
+    if (tid < NRP * 16) {
+      const int iya = 16 * ys - 3 + 2 * cRp;
+      const bool oka = (unsigned)iya < (unsigned)kPatch;
+      const bool okb = (unsigned)(iya + 1) < (unsigned)kPatch && cRp < 10;  // window row 21 does not exist
+      unsigned da[7], db[7];
+      {
+        const u32x2 a0 = *reinterpret_cast<const u32x2*>(craw), a1 = *reinterpret_cast<const u32x2*>(craw + 8),
+                    a2 = *reinterpret_cast<const u32x2*>(craw + 16);
+        const u32x2 b0 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH),
+                    b1 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 8),
+                    b2 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 16);
+        da[0] = a0[0], da[1] = a0[1], da[2] = a1[0], da[3] = a1[1], da[4] = a2[0], da[5] = a2[1];
+        db[0] = b0[0], db[1] = b0[1], db[2] = b1[0], db[3] = b1[1], db[4] = b2[0], db[5] = b2[1];
+        da[6] = *reinterpret_cast<const unsigned*>(craw + 24);
+        db[6] = *reinterpret_cast<const unsigned*>(craw + RAW_PITCH + 24);
+      }
+      const int xin0 = 112 * side - 5 + 8 * cxg;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        unsigned o[8];
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+          const int w = 1 + 3 * px + c;  // byte inside the dword run
+          const bool okx = (unsigned)(xin0 + px) < (unsigned)kPatch;
+          const float fa = (float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu) * (1.0f / 128.0f) - 1.0f;
+          const float fb = (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu) * (1.0f / 128.0f) - 1.0f;
+          o[px] = PackPair<T>::pack((oka && okx) ? fa : pvc[c], (okb && okx) ? fb : pvc[c]);
+        }
+        *reinterpret_cast<u32x4*>(cdst + c * PLANE) = u32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x4*>(cdst + c * PLANE + 16) = u32x4{o[4], o[5], o[6], o[7]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // patch complete; raw rows free
+#ifdef HIPAC_ABL_STRIP_NO_DMA
+    if (n_strips < 0)
+#endif
+    if (g + 1 < n_steps) {
+      const int gn = g + 1;
+      issue_dma(blockIdx.x + (gn / kStripSteps) * gridDim.x, gn % kStripSteps);  // lands behind the MFMA loop
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+#ifdef HIPAC_ABL_STRIP_NO_MFMA
+    if (n_strips < 0)
+#endif
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const int c = s >> 2, rp = s & 3;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned char* p = fbase + (c * NRP + i + rp) * (PXW * 4);
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
+        const frag af = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        acc[i] = E::mfma(wreg[s], af, acc[i]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue: y max in registers, + bias, ReLU, round to T, x max across lanes, store -------
+#ifdef HIPAC_ABL_STRIP_NO_EPI
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i]));
+    if (n_strips < 0)
+#endif
+    {
+    if (ys == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) carry[e] = -3.0e38f;  // stem row -1 lies outside the image
+    }
+    float4 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(bias + jt * 32 + 8 * q + 4 * h);
+    const bool first_col = (side == 0 && st == 0 && r == 0);  // stem column -1: outside the image
+    const int px = 28 * side + 14 * st + (r >> 1);
+    const bool writer = (r & 1) == 0 && r <= 26;
+    unsigned pk[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int e = 4 * cq + t;
+          const float top = q == 0 ? carry[e] : acc[2 * q - 1][e];
+          v[t] = fmaxf(fmaxf(top, acc[2 * q][e]), acc[2 * q + 1][e]);
+        }
+        v[0] = fmaxf(v[0] + bv[cq].x, 0.f);
+        v[1] = fmaxf(v[1] + bv[cq].y, 0.f);
+        v[2] = fmaxf(v[2] + bv[cq].z, 0.f);
+        v[3] = fmaxf(v[3] + bv[cq].w, 0.f);
+        pk[q][2 * cq] = first_col ? 0u : PackPair<T>::pack_rn(v[0], v[1]);
+        pk[q][2 * cq + 1] = first_col ? 0u : PackPair<T>::pack_rn(v[2], v[3]);
+      }
+    }
+    carry = acc[7];
+    // x max: lane r takes lanes r+1 and r+2 (stem columns to its right) by two DPP wave shifts -- no LDS, no
+    // waits.  Values are post-ReLU (>= +0): their 16-bit patterns order like unsigned integers.
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const unsigned a0 = pk[q][d];
+        const unsigned a1 = __builtin_amdgcn_update_dpp(0u, a0, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        const unsigned a2 = __builtin_amdgcn_update_dpp(0u, a1, 0x130, 0xf, 0xf, false);
+        const u16x2 m = __builtin_elementwise_max(
+            __builtin_bit_cast(u16x2, a0),
+            __builtin_elementwise_max(__builtin_bit_cast(u16x2, a1), __builtin_bit_cast(u16x2, a2)));
+        pk[q][d] = __builtin_bit_cast(unsigned, m);
+      }
+    if (writer) {
+      T* const dst0 = out + ((((size_t)b * 56 + 4 * ys) * 56 + px) * 64 + jt * 32 + 4 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+          *reinterpret_cast<u32x2*>(dst0 + (size_t)q * (56 * 64) + 8 * cq) = u32x2{pk[q][2 * cq], pk[q][2 * cq + 1]};
+    }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // layer1 kernel: 3x3 / stride 1 / 64 -> 64 channels on the 56x56 map (4 of the 20 convs,
 // 25 % of the FLOPs, and the largest activations after the stem).
 //   * persistent workgroups (grid-stride over work units), 4 waves
@@ -1850,7 +2114,13 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     if (ops.take()) {
       const int n_tiles = ne * kStemTilesPerImage;
       const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent: 2 workgroups per CU
-      if (p.u8_input)
+      if (p.u8_input && p.stem_strip) {
+        const int n_strips = 2 * ne;
+        const int sgrid = n_strips < 512 ? n_strips : 512;  // persistent: 2 workgroups per CU
+        hipLaunchKernelGGL((stem_pool_strip_kernel<T>), dim3(sgrid), dim3(256), 0, s, (const unsigned char*)xin,
+                           (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
+                           ne * kPatch * kPatch * 3, net.stem_pad[0], net.stem_pad[1], net.stem_pad[2]);
+      } else if (p.u8_input)
         hipLaunchKernelGGL((stem_pool_kernel<T, true>), dim3(grid), dim3(256), 0, s, xin, (const T*)net.stem.w,
                            net.stem.bias, (T*)(ws + p.pool), n_tiles, net.lut_t,
                            (long long)ne * kPatch * kPatch * 3);

@@ -59,6 +59,7 @@ Plan make_plan(int batch, int precision) {
   const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
   p.fuse_stem = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
+  p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -250,6 +251,63 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
   return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
 }
 
+// Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
+// pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds
+// x'' = v/128 - 1, so w'' = w * scale * 128 / (255 std_c) and the bias takes - sum w'' mu''_c with
+// mu''_c = (255 mean_c - 128)/128 over ALL 49 taps (a pixel outside the image carries mu''_c = the
+// normalised 0 the reference pads with).  The fold uses the ROUNDED weights, so what is left of the
+// weight rounding multiplies the centred value x'' - mu'', as in the unfolded form.
+// K order: k = 16 s + 8 h + j, s = 4 c + rp, kh = 2 rp + (j & 1), kw = 4 h + (j >> 1); kh, kw = 7 are zero.
+static float round_to(float v, int precision) {
+  const uint16_t b = to_bits(v, precision);
+  if (precision == HIPAC_PREC_BF16) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  }
+  _Float16 hh;
+  memcpy(&hh, &b, 2);
+  return (float)hh;
+}
+static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW* out, float pad[3]) {
+  const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+  std::vector<uint16_t> w((size_t)64 * 192, 0);
+  std::vector<float> bias(64);
+  double mu[3];
+  for (int ch = 0; ch < 3; ++ch) {
+    mu[ch] = (255.0 * mean[ch] - 128.0) / 128.0;
+    pad[ch] = round_to((float)mu[ch], precision);
+  }
+  for (int o = 0; o < 64; ++o) {
+    const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
+    double b = (double)c.bn_beta[o] - (double)c.bn_mean[o] * scale;
+    for (int ch = 0; ch < 3; ++ch)
+      for (int kh = 0; kh < 7; ++kh)
+        for (int kw = 0; kw < 7; ++kw) {
+          const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale * 128.0 / (255.0 * stdv[ch]);
+          const int s = 4 * ch + (kh >> 1), hq = kw >> 2, j = 2 * (kw & 3) + (kh & 1);
+          const uint16_t bits = to_bits((float)v, precision);
+          w[(size_t)o * 192 + 16 * s + 8 * hq + j] = bits;
+          uint16_t tmp = bits;
+          float rounded;
+          if (precision == HIPAC_PREC_BF16) {
+            const uint32_t u = (uint32_t)tmp << 16;
+            memcpy(&rounded, &u, 4);
+          } else {
+            _Float16 hh;
+            memcpy(&hh, &tmp, 2);
+            rounded = (float)hh;
+          }
+          b -= (double)rounded * mu[ch];
+        }
+    bias[o] = (float)b;
+  }
+  int rc = upload(w.data(), w.size() * 2, &out->w);
+  if (rc) return rc;
+  return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
+}
+
 static void free_convw(ConvW& c) {
   if (c.w) (void)hipFree(c.w);
   if (c.bias) (void)hipFree(c.bias);
@@ -301,6 +359,7 @@ const char* hipac_last_error(void) { return g_err; }
 void hipac_weights_free(hipac_weights_t* w) {
   if (!w) return;
   free_convw(w->net.stem);
+  free_convw(w->net.stem_u8);
   for (int i = 0; i < 8; ++i)
     for (int j = 0; j < 2; ++j) free_convw(w->net.block[i][j]);
   for (int i = 0; i < 3; ++i) free_convw(w->net.down[i]);
@@ -326,6 +385,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   w->net.num_classes = params->num_classes;
   const float eps = params->bn_eps;
   int rc = pack_conv(params->stem, 64, 3, 7, eps, precision, true, &w->net.stem);
+  if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8, w->net.stem_pad);
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];

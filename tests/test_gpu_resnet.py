@@ -115,12 +115,21 @@ def test_native_layout_equals_nchw_path_bitwise():
     assert torch.equal(f1, f2) and torch.equal(l1, l2)
 
 
-def test_uint8_input_equals_normalize_then_forward_bitwise():
-    """in_layout = uint8 HWC (normalise fused into the stem) == patches_normalize -> native forward."""
-    sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
-    u8 = synth.synth_patches_u8(7, seed=21).cuda()
+def _border_patches(n, seed):
+    u8 = synth.synth_patches_u8(n, seed=seed)
     u8[0, :5] = 0
     u8[1, :, -3:] = 255  # extreme values at the borders
+    u8[2, -4:, :] = 255
+    u8[2, :, :2] = 0
+    return u8
+
+
+def test_uint8_table_kernel_equals_normalize_then_forward_bitwise(monkeypatch):
+    """HIPAC_STEM_STRIP=0: in_layout = uint8 HWC with the first-form stem kernel (normalise through the LDS
+    table) == patches_normalize -> native forward, bit for bit."""
+    monkeypatch.setenv("HIPAC_STEM_STRIP", "0")
+    sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
+    u8 = _border_patches(7, 21).cuda()
     for prec in ("bf16", "fp16"):
         net = capi.PackedResNet18(sd, precision=prec)
         f1, l1, lab1 = net.forward(capi.patches_normalize(u8, prec), want_logits=True, want_labels=True, native_layout=True)
@@ -130,6 +139,27 @@ def test_uint8_input_equals_normalize_then_forward_bitwise():
         assert torch.equal(f1, f2) and torch.equal(l1, l2) and torch.equal(lab1, lab2)
     with pytest.raises(capi.HipacError):
         net.forward(torch.zeros((2, 200, 224, 3), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_uint8_strip_kernel_against_oracle(prec):
+    """The default uint8 path (strip kernel: normalisation folded into the stem weights, pooling in
+    registers): its pooled stem map, features and logits against the oracle, on patches with extreme
+    values along all four borders, and at a batch that gives one workgroup several strips."""
+    sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
+    u8 = _border_patches(7, 21)
+    x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+    taps = {}
+    ref_f, ref_l = R.resnet18_forward(x, sd, taps)
+    net = capi.PackedResNet18(sd, precision=prec)
+    f, l, _ = net.forward(u8.cuda(), want_logits=True)
+    assert rel(net.tap(7, 1), taps["maxpool"]) <= TOL[prec]["tap"]
+    assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
+    big = synth.synth_patches_u8(300, seed=5)  # 600 strips: workgroups walk more than one strip
+    xb = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in big[[0, 150, 299]]])
+    ref_fb, _ = R.resnet18_forward(xb, sd)
+    fb, _, _ = net.forward(big.cuda(), want_logits=True)
+    assert rel(fb[[0, 150, 299]], ref_fb) <= TOL[prec]["out"]
 
 
 def test_sub_batching_and_determinism(monkeypatch):
