@@ -1169,13 +1169,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused stem, uint8 input, second form ("strip" kernel): the same 7x7/2 conv + BN + ReLU + 3x3/2
-// max-pool on raw uint8 HWC patches, restructured so that NOTHING but the MFMA loop is expensive:
+// Fused stem, uint8 input, second form ("strip" kernel, stem_pool_strip2_kernel below): the same 7x7/2 conv +
+// BN + ReLU + 3x3/2 max-pool on raw uint8 HWC patches, restructured around the MFMA loop:
 //   * ToTensor / Normalize are folded into the weights and the bias at pack time: the kernel
-//     multiplies x'' = v/128 - 1 (exact in bf16 and fp16) by w'' = w * 128 / (255 std_c) and the bias
-//     carries -sum(w'' mu''_c), mu''_c = (255 mean_c - 128)/128; pixels outside the image take the
-//     value mu''_c (rounded to T), i.e. the normalised 0 the reference pads with.  No table, no
-//     per-pixel rounding of the input.
+//     multiplies the byte value v itself (exact in bf16 and fp16) by w'' = w / (255 std_c) and the bias
+//     carries -sum(w'' mu''_c), mu''_c = 255 mean_c; pixels outside the image take the value mu''_c
+//     (rounded to T), i.e. the normalised 0 the reference pads with.  No table, no per-pixel
+//     rounding of the input.
 //   * K is packed as (channel plane c, row pair rp, column quad cq) = 3 x 4 x 2 fragments of 8
 //     = 192 (147 real), 12 k16 steps instead of 14.  In LDS a plane holds, per column, the two rows
 //     of a row pair in one dword, so the fragment of stem column sx (input columns 2sx-3+4cq ..+3,
@@ -1225,211 +1225,313 @@ template <> struct PackPair<__bf16> {
 
 constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 
+// ---------------------------------------------------------------------------------------
+// Schedule: ONE 8-wave workgroup per CU holds two TEAMS of four waves (team = wave >> 2, i.e. the two
+// waves that share a SIMD belong to different teams).  A team works on its own strips with its own LDS;
+// its step is cut into two halves that alternate behind ONE workgroup barrier per half:
+//     H1(n): request the input rows of step n+1 (LDS-DMA) . the 96-MFMA loop of step n
+//     H2(n): epilogue of step n (pooling in registers, store) . conversion of the rows of step n+1
+// and team B runs one half behind team A: whenever one wave of a SIMD is in its MFMA loop its partner is
+// in the VALU / LDS / store half -- matrix beside vector work, never matrix beside matrix.  Every wave
+// converts exactly the raw rows it requested itself (its own counted vmcnt orders them), so no barrier
+// is needed inside a half.  The bias is the initial accumulator; ReLU is one packed integer max after
+// the x max; the pooled rows leave through per-wave LDS staging as 64 contiguous bytes per pixel.
+// ---------------------------------------------------------------------------------------
+#ifndef HIPAC_STRIP_PRIO
+#define HIPAC_STRIP_PRIO 2  // 0: no s_setprio, 1: around the MFMA loop, 2: on the vector half
+#endif
 template <typename T>
-__global__ __launch_bounds__(256, 2) void stem_pool_strip_kernel(const unsigned char* __restrict__ x,
-                                                                 const T* __restrict__ wgt,
-                                                                 const float* __restrict__ bias, T* __restrict__ out,
-                                                                 int n_strips, int in_bytes, float pv0, float pv1,
-                                                                 float pv2) {
+__global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned char* __restrict__ x,
+                                                                  const T* __restrict__ wgt,
+                                                                  const float* __restrict__ bias, T* __restrict__ out,
+                                                                  int n_strips, int in_bytes, float pv0, float pv1,
+                                                                  float pv2) {
   using E = Elem<T>;
   using frag = typename E::frag;
-  constexpr int NRP = 11, PXW = 128;                  // row pairs per step, window columns
-  constexpr int PLANE = NRP * PXW * 4;                // bytes of one channel plane
+  constexpr int NRP = 11, PXW = 128;
+  constexpr int PLANE = NRP * PXW * 4;
   constexpr int PATCH_BYTES = 3 * PLANE;              // 16 896
-  constexpr int RAW_PITCH = 528, RAW_ROWS = 22;       // 2 DMA pieces of 256 B per row + 16 B; row 21 = never written
-  constexpr int RAW_BYTES = RAW_ROWS * RAW_PITCH;
-  constexpr int NPIECE = 21 * 2;                      // DMA pieces (256 B) per step
-  constexpr int PPW = (NPIECE + 3) / 4;               // pieces per wave (11; waves 2, 3 have 10)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCH_BYTES + RAW_BYTES];
-  unsigned char* const Pl = smem;
-  unsigned char* const Rl = smem + PATCH_BYTES;
+  constexpr int RAW_PITCH = 528, RAW_ROWS = 22;
+  constexpr int RAW_BYTES = RAW_ROWS * RAW_PITCH;     // 11 616
+  constexpr int TEAM_BYTES = PATCH_BYTES + RAW_BYTES;
+  constexpr int CARRY_BYTES = 512 * 64;               // per lane 16 floats: the raw last stem row of the previous step
+  constexpr int STG_BYTES = 4 * 14 * 64;              // per wave: 4 pooled rows x 14 pixels x 32 channels of T
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 256];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int jt = wave & 1, st = wave >> 1;  // channel half, 14-column half of the strip
+  const int team = wave >> 2, tw = wave & 3;          // team, wave inside the team
+  const int jt = tw & 1, st = tw >> 1;                // channel half, 14-column half of the strip
   const int r = lane & 31, h = lane >> 5;
+  unsigned char* const Pl = smem + team * TEAM_BYTES;
+  unsigned char* const Rl = Pl + PATCH_BYTES;
+  unsigned char* const Cl = smem + 2 * TEAM_BYTES + tid * 16;  // chunk k of this lane at + k * 8192 (conflict-free)
+  // output staging of this wave (private: no barrier): [pooled row q][pixel k][64 B]; written by the lanes that
+  // hold a pooled pixel (8 bytes each), read back as 224 linear 16-byte chunks and stored 64 contiguous
+  // bytes per pixel -- per-lane 8-byte stores to 28 different lines cost 2 700 cycles per step
+  unsigned char* const Sl = smem + 2 * TEAM_BYTES + CARRY_BYTES + wave * STG_BYTES;
+  // bias in LDS: a global load inside the step loop would wait (vmcnt retires in order) for the rows just requested
+  float* const Bl = reinterpret_cast<float*>(smem + 2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES);
+  if (tid < 64) Bl[tid] = bias[tid];  // visible after the first phase barrier (first read: H1(0))
+  int s_off[4];  // element offset of chunk lane + 64 m from the step's first pixel
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = lane + 64 * m, pix = c >> 2;
+    const int q = (pix * 147) >> 11, k = pix - 14 * q;
+    s_off[m] = (q * 56 + k) * 64 + (c & 3) * 8;
+  }
 
-  // this lane's rows of the packed weight matrix: channel 32 jt + r, k = 16 s + 8 h .. + 7, s = 0..11
   frag wreg[12];
   {
     const char* wb = reinterpret_cast<const char*>(wgt) + (size_t)(jt * 32 + r) * (192 * 2) + 16 * h;
 #pragma unroll
     for (int s = 0; s < 12; ++s) wreg[s] = *reinterpret_cast<const frag*>(wb + s * 32);
 #pragma unroll
-    for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(wreg[s]));  // the loads retire here, not inside the step loop
+    for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(wreg[s]));
   }
   const rsrc_t in_rsrc = make_rsrc(x, in_bytes);
 
-  // DMA of the 21 input rows of step (strip, ys): window row w = input row 16 ys - 3 + w, window
-  // column 0 = input column 112 side - 5; the dword-aligned run starts one byte earlier (3 X0 - 1 is a
-  // multiple of 4 for both sides).  Rows outside the image and bytes outside the tensor read as zeros
-  // (descriptor range check); the conversion replaces whatever lies outside the image anyway.
+  // rows owned by this wave: window rows 6 tw .. 6 tw + 5 (row pairs 3 tw .. 3 tw + 2); wave 3 owns rows
+  // 18 .. 20 (row 21 does not exist)
+  const int own_rows = tw < 3 ? 6 : 3;
   auto issue_dma = [&](int strip, int ys) {
     const int b = strip >> 1, side = strip & 1;
     const int base = b * (kPatch * kPatch * 3) + (16 * ys - 3) * (kPatch * 3) + 3 * (112 * side - 5) - 1;
-    static_for<PPW>([&](auto K) {
+    static_for<6>([&](auto K) {
       constexpr int k = decltype(K)::value;
-      const int p = wave + 4 * k;
-      if (p < NPIECE) {
-        const int row = p >> 1, half = p & 1;
+      if (k < own_rows) {
+        const int row = 6 * tw + k;
         const int iy = 16 * ys - 3 + row;
         const bool ok = (unsigned)iy < (unsigned)kPatch;
-        const int off = base + row * (kPatch * 3) + (half * 64 + lane) * 4;
-        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH + half * 256, ok ? off : (int)0x80000000, 0);
+        const int off = base + row * (kPatch * 3) + lane * 4;
+        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH, ok ? off : (int)0x80000000, 0);
+        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH + 256, ok ? off + 256 : (int)0x80000000, 0);
       }
     });
   };
 
-  // conversion task of this thread (threads 0..175): row pair cRp, 8-column group cxg
-  const int cRp = tid >> 4, cxg = tid & 15;
+  // conversion task of this lane: row pair 3 tw + (lane >> 4) (lanes 48..63 idle; wave 3: lanes 32..63), 8 columns
+  const int cRp = 3 * tw + (lane >> 4), cxg = lane & 15;
+  const bool ctask = (lane >> 4) < (tw < 3 ? 3 : 2);
   const unsigned char* const craw = Rl + (2 * cRp) * RAW_PITCH + cxg * 24;
   unsigned char* const cdst = Pl + cRp * (PXW * 4) + cxg * 32;
-  const float pvc[3] = {pv0, pv1, pv2};
-
-  // fragment base of this lane: window column 2 r + 56 st (+ 4 for the second column quad)
-  const unsigned char* const fbase = Pl + (2 * r + 56 * st) * 4 + 16 * h;
-
-  f32x16 carry;  // raw accumulators of the last stem row of the previous step
-  const int n_steps = ((n_strips - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * kStripSteps;
-  if ((int)blockIdx.x < n_strips) issue_dma(blockIdx.x, 0);
-  for (int g = 0; g < n_steps; ++g) {
-    const int strip = blockIdx.x + (g / kStripSteps) * gridDim.x;
-    const int ys = g % kStripSteps;
-    const int b = strip >> 1, side = strip & 1;
-    // this wave's DMA pieces of the step have landed once only the 16 stores of the previous epilogue
-    // (issued later: vmcnt retires in order) are still outstanding
-    if (g == 0) wait_vmcnt<0>();
-    else wait_vmcnt<16>();
-    __builtin_amdgcn_s_barrier();  // this step's raw rows landed; every wave is past the previous MFMA loop
-#ifdef HIPAC_ABL_STRIP_NO_CONVERT
-    if (n_strips < 0)
-#endif
-    if (tid < NRP * 16) {
-      const int iya = 16 * ys - 3 + 2 * cRp;
-      const bool oka = (unsigned)iya < (unsigned)kPatch;
-      const bool okb = (unsigned)(iya + 1) < (unsigned)kPatch && cRp < 10;  // window row 21 does not exist
-      unsigned da[7], db[7];
-      {
-        const u32x2 a0 = *reinterpret_cast<const u32x2*>(craw), a1 = *reinterpret_cast<const u32x2*>(craw + 8),
-                    a2 = *reinterpret_cast<const u32x2*>(craw + 16);
-        const u32x2 b0 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH),
-                    b1 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 8),
-                    b2 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 16);
-        da[0] = a0[0], da[1] = a0[1], da[2] = a1[0], da[3] = a1[1], da[4] = a2[0], da[5] = a2[1];
-        db[0] = b0[0], db[1] = b0[1], db[2] = b1[0], db[3] = b1[1], db[4] = b2[0], db[5] = b2[1];
-        da[6] = *reinterpret_cast<const unsigned*>(craw + 24);
-        db[6] = *reinterpret_cast<const unsigned*>(craw + RAW_PITCH + 24);
-      }
-      const int xin0 = 112 * side - 5 + 8 * cxg;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        unsigned o[8];
-#pragma unroll
-        for (int px = 0; px < 8; ++px) {
-          const int w = 1 + 3 * px + c;  // byte inside the dword run
-          const bool okx = (unsigned)(xin0 + px) < (unsigned)kPatch;
-          const float fa = (float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu) * (1.0f / 128.0f) - 1.0f;
-          const float fb = (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu) * (1.0f / 128.0f) - 1.0f;
-          o[px] = PackPair<T>::pack((oka && okx) ? fa : pvc[c], (okb && okx) ? fb : pvc[c]);
-        }
-        *reinterpret_cast<u32x4*>(cdst + c * PLANE) = u32x4{o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<u32x4*>(cdst + c * PLANE + 16) = u32x4{o[4], o[5], o[6], o[7]};
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // patch complete; raw rows free
-#ifdef HIPAC_ABL_STRIP_NO_DMA
-    if (n_strips < 0)
-#endif
-    if (g + 1 < n_steps) {
-      const int gn = g + 1;
-      issue_dma(blockIdx.x + (gn / kStripSteps) * gridDim.x, gn % kStripSteps);  // lands behind the MFMA loop
-    }
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    __builtin_amdgcn_s_setprio(1);
-#ifdef HIPAC_ABL_STRIP_NO_MFMA
-    if (n_strips < 0)
-#endif
-#pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const int c = s >> 2, rp = s & 3;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned char* p = fbase + (c * NRP + i + rp) * (PXW * 4);
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
-        const frag af = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
-        acc[i] = E::mfma(wreg[s], af, acc[i]);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    // ---- epilogue: y max in registers, + bias, ReLU, round to T, x max across lanes, store -------
-#ifdef HIPAC_ABL_STRIP_NO_EPI
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i]));
-    if (n_strips < 0)
-#endif
+  const unsigned pvpk[3] = {PackPair<T>::pack(pv0, pv0), PackPair<T>::pack(pv1, pv1), PackPair<T>::pack(pv2, pv2)};
+  auto convert = [&](int strip, int ys) {
+    if (!ctask) return;
+    const int side = strip & 1;
+    unsigned da[7], db[7];
     {
-    if (ys == 0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) carry[e] = -3.0e38f;  // stem row -1 lies outside the image
+      const u32x2 a0 = *reinterpret_cast<const u32x2*>(craw), a1 = *reinterpret_cast<const u32x2*>(craw + 8),
+                  a2 = *reinterpret_cast<const u32x2*>(craw + 16);
+      const u32x2 b0 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH),
+                  b1 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 8),
+                  b2 = *reinterpret_cast<const u32x2*>(craw + RAW_PITCH + 16);
+      da[0] = a0[0], da[1] = a0[1], da[2] = a1[0], da[3] = a1[1], da[4] = a2[0], da[5] = a2[1];
+      db[0] = b0[0], db[1] = b0[1], db[2] = b1[0], db[3] = b1[1], db[4] = b2[0], db[5] = b2[1];
+      da[6] = *reinterpret_cast<const unsigned*>(craw + 24);
+      db[6] = *reinterpret_cast<const unsigned*>(craw + RAW_PITCH + 24);
     }
-    float4 bv[4];
+    // rows outside the image (only at the first and the last step of a strip) and the nonexistent window
+    // row 21: replace the half-dword of that row by the pad value
+    const int iya = 16 * ys - 3 + 2 * cRp;
+    const bool oka = (unsigned)iya < (unsigned)kPatch;
+    const bool okb = (unsigned)(iya + 1) < (unsigned)kPatch && cRp < 10;
+    const unsigned keep = (oka ? 0x0000ffffu : 0u) | (okb ? 0xffff0000u : 0u);
+    const int xin0 = 112 * side - 5 + 8 * cxg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(bias + jt * 32 + 8 * q + 4 * h);
-    const bool first_col = (side == 0 && st == 0 && r == 0);  // stem column -1: outside the image
-    const int px = 28 * side + 14 * st + (r >> 1);
-    const bool writer = (r & 1) == 0 && r <= 26;
-    unsigned pk[4][8];
+    for (int c = 0; c < 3; ++c) {
+      unsigned o[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+      for (int px = 0; px < 8; ++px) {
+        const int w = 1 + 3 * px + c;  // byte inside the dword run
+        const float fa = (float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu);
+        const float fb = (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu);
+        const unsigned v = PackPair<T>::pack(fa, fb);
+        const bool okx = (unsigned)(xin0 + px) < (unsigned)kPatch;
+        o[px] = okx ? ((v & keep) | (pvpk[c] & ~keep)) : pvpk[c];
+      }
+      *reinterpret_cast<u32x4*>(cdst + c * PLANE) = u32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<u32x4*>(cdst + c * PLANE + 16) = u32x4{o[4], o[5], o[6], o[7]};
+    }
+  };
+
+  const unsigned char* const fbase = Pl + (2 * r + 56 * st) * 4 + 16 * h;
+  const int tg = 2 * blockIdx.x + team, tstride = 2 * gridDim.x;   // this team's strips: tg, tg + tstride, ...
+  const int my_strips = tg < n_strips ? (n_strips - tg + tstride - 1) / tstride : 0;
+  const int n_steps = my_strips * kStripSteps;
+  // workgroup-uniform phase count: 2 halves per step + the prologue half, team B one phase behind
+  const int max_strips = (n_strips - 2 * (int)blockIdx.x + tstride - 1) / tstride;  // team A's count >= team B's
+  const int n_phases = 2 * max_strips * kStripSteps + 2;
+
+#ifdef HIPAC_HALO_STAMPS
+  unsigned long long z_sum[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  f32x16 acc[8];
+  const bool first_col_wave = st == 0;  // with side == 0: lane r == 0 is stem column -1
+  for (int p = 0; p < n_phases; ++p) {
+    const int hs = p - team - 1;            // half index of this team: -1 = prologue, 2n = H1(n), 2n+1 = H2(n)
+    HALO_STAMP(z_t0);
+    if (hs >= -1 && hs < 2 * n_steps) {
+      const int n = hs >> 1;                // step (floor: -1 for the prologue)
+      if (hs & 1) {
+        // ---------------- H2(n): epilogue of step n, conversion of step n + 1 ----------------
+#if HIPAC_STRIP_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);  // the vector half goes first: its partner needs one issue slot per 32 cycles
+#endif
+        const int strip = tg + ((n < 0 ? 0 : n) / kStripSteps) * tstride;
+        const int ys = (n < 0 ? 0 : n) % kStripSteps;
+        if (n >= 0) {
+          const int b = strip >> 1, side = strip & 1;
+          f32x16 carry;
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq) {
-        float v[4];
+          for (int k = 0; k < 4; ++k) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(Cl + k * 8192);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int e = 4 * cq + t;
-          const float top = q == 0 ? carry[e] : acc[2 * q - 1][e];
-          v[t] = fmaxf(fmaxf(top, acc[2 * q][e]), acc[2 * q + 1][e]);
+            for (int t = 0; t < 4; ++t) carry[4 * k + t] = ys == 0 ? -3.0e38f : cv[t];  // stem row -1 lies outside the image
+          }
+          const bool writer = (r & 1) == 0 && r <= 26;
+          const bool col_m1 = side == 0 && first_col_wave && r == 0;  // this lane holds stem column -1
+#ifdef HIPAC_ABL_STRIP_STORE_LOCAL
+          T* const dst0 = out + (size_t)blockIdx.x * 16384 + jt * 32 + (b & 0);
+#else
+          T* const dst0 = out + ((((size_t)b * 56 + 4 * ys) * 56 + 28 * side + 14 * st) * 64 + jt * 32);
+#endif
+          typedef __attribute__((ext_vector_type(2))) short s16x2;
+          // one pooled row at a time: y max (fp32, v_max3), round to T, then the x max of lanes r, r+1, r+2 by two
+          // DPP wave shifts and ReLU, both on the 16-bit patterns as SIGNED integers -- among non-negative
+          // floats that is the float order, every negative float is below every non-negative one, and the
+          // final max with +0 removes whatever negative value is left
+          static_for<4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            unsigned pk[8];
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+              float v[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int e = 4 * cq + t;
+                const float top = q == 0 ? carry[e] : acc[q == 0 ? 0 : 2 * q - 1][e];
+                v[t] = fmaxf(fmaxf(top, acc[2 * q][e]), acc[2 * q + 1][e]);
+              }
+              pk[2 * cq] = PackPair<T>::pack_rn(v[0], v[1]);
+              pk[2 * cq + 1] = PackPair<T>::pack_rn(v[2], v[3]);
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+              const unsigned a0 = col_m1 ? 0x80008000u : pk[d];  // -0.0: below every value as int16, never wins
+              const unsigned a1 = __builtin_amdgcn_update_dpp(0u, a0, 0x130, 0xf, 0xf, false);  // wave_shl:1
+              const s16x2 t1 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, a0), __builtin_bit_cast(s16x2, a1));
+              const unsigned u2 = __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, t1), 0x130, 0xf, 0xf, false);
+              const s16x2 t2 = __builtin_elementwise_max(t1, __builtin_bit_cast(s16x2, u2));
+              pk[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t2, s16x2{0, 0}));
+            }
+            if (writer) {
+#pragma unroll
+              for (int cq = 0; cq < 4; ++cq)
+                *reinterpret_cast<u32x2*>(Sl + (q * 14 + (r >> 1)) * 64 + cq * 16 + h * 8) = u32x2{pk[2 * cq], pk[2 * cq + 1]};
+            }
+          });
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<f32x4*>(Cl + k * 8192) = f32x4{acc[7][4 * k], acc[7][4 * k + 1], acc[7][4 * k + 2], acc[7][4 * k + 3]};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's staging writes (LDS operations of a wave complete in order)
+#ifdef HIPAC_ABL_STRIP_NO_STORE
+          if (n_strips < 0)
+#endif
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (m < 3 || lane < 32)
+              *reinterpret_cast<u32x4*>(dst0 + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
         }
-        v[0] = fmaxf(v[0] + bv[cq].x, 0.f);
-        v[1] = fmaxf(v[1] + bv[cq].y, 0.f);
-        v[2] = fmaxf(v[2] + bv[cq].z, 0.f);
-        v[3] = fmaxf(v[3] + bv[cq].w, 0.f);
-        pk[q][2 * cq] = first_col ? 0u : PackPair<T>::pack_rn(v[0], v[1]);
-        pk[q][2 * cq + 1] = first_col ? 0u : PackPair<T>::pack_rn(v[2], v[3]);
+        HALO_STAMP(z_te);
+#ifdef HIPAC_HALO_STAMPS
+        if (n >= 0) z_sum[1] += z_te - z_t0, z_sum[4] += 1;
+#endif
+        if (n + 1 < n_steps) {
+          const int gn = n + 1;
+          if (n < 0) {
+            issue_dma(tg, 0);  // prologue: nothing was requested yet
+            wait_vmcnt<0>();
+          } else {
+            wait_vmcnt<4>();  // this wave's raw rows of step n+1 (requested in H1(n)) are older than its 4 stores
+          }
+          HALO_STAMP(z_tw);
+          convert(tg + (gn / kStripSteps) * tstride, gn % kStripSteps);
+#ifdef HIPAC_HALO_STAMPS
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          HALO_STAMP(z_tc);
+          if (n >= 0) z_sum[2] += z_tw - z_te, z_sum[3] += z_tc - z_tw;
+#endif
+        }
+      } else {
+        // ---------------- H1(n): request the rows of step n + 1, MFMA loop of step n ----------------
+#ifdef HIPAC_ABL_STRIP_NO_DMA
+        if (n_strips < 0)
+#endif
+        if (n + 1 < n_steps) {
+          const int gn = n + 1;
+          issue_dma(tg + (gn / kStripSteps) * tstride, gn % kStripSteps);
+        }
+        {
+          float4 bv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(Bl + jt * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[i][4 * q + 0] = bv[q].x;
+              acc[i][4 * q + 1] = bv[q].y;
+              acc[i][4 * q + 2] = bv[q].z;
+              acc[i][4 * q + 3] = bv[q].w;
+            }
+        }
+#if HIPAC_STRIP_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const int c = s >> 2, rp = s & 3;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const unsigned char* pp = fbase + (c * NRP + i + rp) * (PXW * 4);
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(pp), hi = *reinterpret_cast<const u32x2*>(pp + 8);
+            const frag af = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            acc[i] = E::mfma(wreg[s], af, acc[i]);
+          }
+        }
+#if HIPAC_STRIP_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef HIPAC_HALO_STAMPS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i]));
+        HALO_STAMP(z_tm);
+        z_sum[0] += z_tm - z_t0;
+#endif
       }
     }
-    carry = acc[7];
-    // x max: lane r takes lanes r+1 and r+2 (stem columns to its right) by two DPP wave shifts -- no LDS, no
-    // waits.  Values are post-ReLU (>= +0): their 16-bit patterns order like unsigned integers.
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const unsigned a0 = pk[q][d];
-        const unsigned a1 = __builtin_amdgcn_update_dpp(0u, a0, 0x130, 0xf, 0xf, false);  // wave_shl:1
-        const unsigned a2 = __builtin_amdgcn_update_dpp(0u, a1, 0x130, 0xf, 0xf, false);
-        const u16x2 m = __builtin_elementwise_max(
-            __builtin_bit_cast(u16x2, a0),
-            __builtin_elementwise_max(__builtin_bit_cast(u16x2, a1), __builtin_bit_cast(u16x2, a2)));
-        pk[q][d] = __builtin_bit_cast(unsigned, m);
-      }
-    if (writer) {
-      T* const dst0 = out + ((((size_t)b * 56 + 4 * ys) * 56 + px) * 64 + jt * 32 + 4 * h);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq)
-          *reinterpret_cast<u32x2*>(dst0 + (size_t)q * (56 * 64) + 8 * cq) = u32x2{pk[q][2 * cq], pk[q][2 * cq + 1]};
-    }
-    }
+    HALO_STAMP(z_tb0);
+#if HIPAC_STRIP_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // half boundary: patch written <-> patch read, for both teams
+#ifdef HIPAC_HALO_STAMPS
+    HALO_STAMP(z_tb1);
+    z_sum[5] += z_tb1 - z_tb0;
+#endif
   }
+#ifdef HIPAC_HALO_STAMPS
+  if (lane == 0) {
+    atomicAdd(&g_halo_stamps[0], z_sum[0]);  // H1: DMA issue + bias + MFMA loop
+    atomicAdd(&g_halo_stamps[1], z_sum[1]);  // H2: epilogue
+    atomicAdd(&g_halo_stamps[2], z_sum[2]);  // H2: wait for the raw rows
+    atomicAdd(&g_halo_stamps[4], z_sum[3]);  // H2: conversion
+    atomicAdd(&g_halo_stamps[5], z_sum[5]);  // barrier waits
+    atomicAdd(&g_halo_stamps[3], z_sum[4]);  // wave-steps
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2116,8 +2218,9 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent: 2 workgroups per CU
       if (p.u8_input && p.stem_strip) {
         const int n_strips = 2 * ne;
-        const int sgrid = n_strips < 512 ? n_strips : 512;  // persistent: 2 workgroups per CU
-        hipLaunchKernelGGL((stem_pool_strip_kernel<T>), dim3(sgrid), dim3(256), 0, s, (const unsigned char*)xin,
+        const int n_pairs = (n_strips + 1) / 2;
+        const int sgrid = n_pairs < 256 ? n_pairs : 256;  // persistent: one 8-wave workgroup (two teams) per CU
+        hipLaunchKernelGGL((stem_pool_strip2_kernel<T>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
                            (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
                            ne * kPatch * kPatch * 3, net.stem_pad[0], net.stem_pad[1], net.stem_pad[2]);
       } else if (p.u8_input)

@@ -252,10 +252,10 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
 }
 
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
-// pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds
-// x'' = v/128 - 1, so w'' = w * scale * 128 / (255 std_c) and the bias takes - sum w'' mu''_c with
-// mu''_c = (255 mean_c - 128)/128 over ALL 49 taps (a pixel outside the image carries mu''_c = the
-// normalised 0 the reference pads with).  The fold uses the ROUNDED weights, so what is left of the
+// pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the byte
+// value v itself (exact in bf16 and fp16), so w'' = w * scale / (255 std_c) and the bias takes
+// - sum w'' mu''_c with mu''_c = 255 mean_c over ALL 49 taps (a pixel outside the image carries mu''_c =
+// the normalised 0 the reference pads with).  The fold uses the ROUNDED weights, so what is left of the
 // weight rounding multiplies the centred value x'' - mu'', as in the unfolded form.
 // K order: k = 16 s + 8 h + j, s = 4 c + rp, kh = 2 rp + (j & 1), kw = 4 h + (j >> 1); kh, kw = 7 are zero.
 static float round_to(float v, int precision) {
@@ -276,7 +276,7 @@ static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW
   std::vector<float> bias(64);
   double mu[3];
   for (int ch = 0; ch < 3; ++ch) {
-    mu[ch] = (255.0 * mean[ch] - 128.0) / 128.0;
+    mu[ch] = 255.0 * mean[ch];
     pad[ch] = round_to((float)mu[ch], precision);
   }
   for (int o = 0; o < 64; ++o) {
@@ -285,7 +285,7 @@ static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW
     for (int ch = 0; ch < 3; ++ch)
       for (int kh = 0; kh < 7; ++kh)
         for (int kw = 0; kw < 7; ++kw) {
-          const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale * 128.0 / (255.0 * stdv[ch]);
+          const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale / (255.0 * stdv[ch]);
           const int s = 4 * ch + (kh >> 1), hq = kw >> 2, j = 2 * (kw & 3) + (kh & 1);
           const uint16_t bits = to_bits((float)v, precision);
           w[(size_t)o * 192 + 16 * s + 8 * hq + j] = bits;
