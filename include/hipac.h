@@ -20,8 +20,16 @@
  *   - return value: 0 on success, otherwise a hipError_t value or one of the
  *     HIPAC_E* codes; nothing throws across the ABI; hipac_last_error() gives
  *     a thread-local message for the last failure
- *   - re-entrant: no global mutable state; a weights handle may be used from
- *     several streams concurrently (read-only)
+ *   - re-entrant: the library keeps no mutable state between calls except the
+ *     thread-local error string; a weights handle is read-only after packing and
+ *     may be used from several streams concurrently (large forwards of one handle
+ *     share its second launch lane, a stream created at pack time: they stay
+ *     correct -- fork / join is by events -- but serialise on that lane)
+ *   - a handle belongs to the device that was current in hipac_resnet18_pack;
+ *     calling it with another device current returns HIPAC_EINVAL
+ *   - developer knobs (HIPAC_SUBBATCH, HIPAC_GROUP, HIPAC_LANES, HIPAC_FUSE_STEM,
+ *     HIPAC_STEM_STRIP) are read from the environment on every call; they select
+ *     among equivalent schedules and must not change while calls are in flight
  */
 #ifndef HIPAC_H_
 #define HIPAC_H_
@@ -275,6 +283,58 @@ int hipac_mil_forward(const hipac_mil_params_t* params, int pooling, const float
 size_t hipac_ntxent_scratch_bytes(int n, int d);
 int hipac_ntxent_fwd_bwd(const float* z, int n, int d, float temperature, float* loss, float* dz,
                          void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Native training step (SURVEY a-12 / a-13): the ResNet18 encoder in TRAIN mode, forward and backward,
+ * fp32 throughout on the exact f32 MFMA.  Replaces what torch autograd executes for
+ *   z_i = model(x_i); z_j = model(x_j); loss.backward()      src/models/simclr.py:88-94
+ *   outputs = model(imgs); scaler.scale(loss).backward()      src/main.py:499-506, :578-586
+ * Batch-norm uses the statistics of the call's own batch (per replica, as nn.DataParallel does: SURVEY F6)
+ * and updates the running statistics with `momentum` (torch: 0.1) and the unbiased variance.
+ *
+ * Parameters live in ONE flat float32 device buffer in a fixed order: 20 convolutions (0 = stem, then per
+ * stage block0.conv1, block0.conv2, [block0.downsample], block1.conv1, block1.conv2), each as
+ *   weight [Cout][Cin][kh][kw] (PyTorch layout), bn.weight [Cout], bn.bias [Cout];
+ * running statistics in a second flat buffer: per conv running_mean [Cout], running_var [Cout];
+ * gradients in a buffer shaped like the parameters.  hipac_train_conv_desc gives geometry and offsets.
+ * ------------------------------------------------------------------------- */
+int hipac_train_num_convs(void);
+int hipac_train_conv_desc(int i, int* cout, int* cin, int* ks, int* stride, int64_t* param_off, int64_t* stat_off);
+size_t hipac_train_param_floats(void);
+size_t hipac_train_stat_floats(void);
+/* Bytes of one forward's workspace (input copy, pre-/post-BN maps of every conv, pool arg-max, batch
+ * statistics, scratch): ~31 MB per image.  The SAME workspace must be handed to the matching backward. */
+size_t hipac_train_workspace_bytes(int batch);
+/* Test tap: byte offset inside the workspace of a map the forward keeps for the backward -- kind 0: output of
+ * conv `conv` before BN, 1: after BN (+ residual) (+ ReLU), both float32 NHWC [batch][H][W][Cout]; 2: pooled stem
+ * map [batch][56][56][64]; 3: batch mean[Cout] then rstd[Cout] of conv `conv`; 4: the max-pool's arg-max bytes
+ * [batch][56][56][64] (0..8 = dy * 3 + dx inside the 3x3 window).  -1 on a bad argument. */
+int64_t hipac_train_debug_offset(int batch, int kind, int conv);
+/* x: float32[batch,3,224,224] NCHW (ImageNet-normalised) -> feats float32[batch,512] (fc = Identity,
+ * src/models/simclr.py:19).  stats (running statistics) may be NULL: not updated.  batch <= 4096. */
+int hipac_train_encoder_forward(const float* params, float* stats, const float* x, int batch, float momentum,
+                                float eps, float* feats, void* workspace, size_t workspace_bytes, void* stream);
+/* dfeats: float32[batch,512] = d loss / d feats of the forward that filled `workspace`.  grads: flat buffer,
+ * overwritten (accumulate = 0) or added to (accumulate = 1: second view of a SimCLR step). */
+int hipac_train_encoder_backward(const float* params, const float* dfeats, int batch, float* grads, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.Linear forward y = x w^T + b (optional ReLU): projector src/models/simclr.py:20-24, fc resnet.py:66. */
+int hipac_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
+                         void* stream);
+/* its backward: dy [M][N] (masked by y > 0 when y, the ReLU output, is given; dym = scratch [M][N] then),
+ * dx [M][K] or NULL, dw [N][K], db [N] or NULL; accumulate = add to dw / db instead of overwriting. */
+int hipac_linear_backward(const float* x, const float* w, const float* dy, const float* y, float* dym, float* dx,
+                          float* dw, float* db, int M, int N, int K, int accumulate, void* stream);
+
+/* nn.CrossEntropyLoss(weight = class_w) value and gradient (src/main.py:490, :552-566): logits [M][C],
+ * labels int64 [M], class_w [C] or NULL, loss float[1], dlogits [M][C], scratch float[2]; all device. */
+int hipac_cross_entropy_fwd_bwd(const float* logits, const int64_t* labels, const float* class_w, int M, int C,
+                                float* loss, float* dlogits, float* scratch, void* stream);
+
+/* torch.optim.Adam step `step` (1-based), no weight decay (src/main.py:492, src/models/simclr.py:79). */
+int hipac_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

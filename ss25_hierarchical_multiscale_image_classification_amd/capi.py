@@ -98,6 +98,25 @@ SYMBOLS = {
                                        C.c_size_t, C.c_void_p]),
     "hipac_mil_forward": (C.c_int, [C.POINTER(MilParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hipac_train_num_convs": (C.c_int, []),
+    "hipac_train_conv_desc": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hipac_train_param_floats": (C.c_size_t, []),
+    "hipac_train_stat_floats": (C.c_size_t, []),
+    "hipac_train_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "hipac_train_debug_offset": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "hipac_train_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hipac_train_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]),
+    "hipac_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "hipac_linear_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hipac_cross_entropy_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "hipac_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_int, C.c_void_p]),
 }
 
 _lib = None
@@ -208,10 +227,12 @@ _STAGE_NAMES = ("layer1", "layer2", "layer3", "layer4")
 class PackedResNet18:
     """Owner of a hipac_weights_t handle (BN-folded, repacked, on device)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], precision: str = "bf16", bn_eps: float = 1e-5):
+    def __init__(self, sd: Dict[str, torch.Tensor], precision: str = "bf16", bn_eps: float = 1e-5,
+                 device: Optional[torch.device] = None):
         """``sd``: bare torchvision-named tensors (conv1.weight, bn1.*, layerK.B.*,
         optional fc.*).  Use ``weights.canonical_state_dict`` to get there from
-        the reference's key layouts."""
+        the reference's key layouts.  ``device``: the ROCm device the handle lives on
+        (default: torch's current device); forwards must be given tensors of that device."""
         if precision not in PRECISIONS:
             raise HipacError(f"precision must be one of {sorted(PRECISIONS)}")
         lib = load_library()
@@ -246,13 +267,16 @@ class PackedResNet18:
             p.fc_b = None
         p.bn_eps = bn_eps
         handle = C.c_void_p()
-        _check(lib.hipac_resnet18_pack(C.byref(p), PRECISIONS[precision], C.byref(handle)), "hipac_resnet18_pack")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            _check(lib.hipac_resnet18_pack(C.byref(p), PRECISIONS[precision], C.byref(handle)), "hipac_resnet18_pack")
         self._lib = lib
         self.handle = handle
         self.precision = precision
         self.num_classes = p.num_classes
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
+        self._stage: Optional[torch.Tensor] = None  # fp32 parity mode: normalised copy of a uint8 batch
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -285,7 +309,14 @@ class PackedResNet18:
                 raise HipacError(f"uint8 input must be [B,224,224,3], got {tuple(x.shape)}")
             layout = IN_U8_HWC
             if self.precision == "fp32":  # parity mode has no fused uint8 stem: normalise first (bit-exact LUT)
-                x, layout, native_layout = patches_normalize(x, "nchw_f32"), IN_NCHW_F32, False
+                # the staging buffer is kept on the object (grow-only), like the workspace: a multi-GB block freed
+                # here while the kernels that read it are still queued could be handed to a caller that fills
+                # its next batch buffer from ANOTHER stream (extract.score_slide does)
+                n_el = x.shape[0] * 3 * PATCH * PATCH
+                if self._stage is None or self._stage.numel() < n_el or self._stage.device != x.device:
+                    self._stage = torch.empty(n_el, dtype=torch.float32, device=x.device)
+                stage = self._stage[:n_el].view(x.shape[0], 3, PATCH, PATCH)
+                x, layout, native_layout = patches_normalize(x, "nchw_f32", out=stage), IN_NCHW_F32, False
         elif native_layout:
             if tuple(x.shape[1:]) != (PAD_H, PAD_W, 4) or x.dtype != TORCH_DTYPE[PRECISIONS[self.precision]]:
                 raise HipacError(f"native input must be {self.precision}[B,{PAD_H},{PAD_W},4], got {x.dtype}{tuple(x.shape)}")
@@ -343,12 +374,16 @@ class PackedResNet18:
 _OUT_FMT = {"nchw_f32": OUT_NCHW_F32, "bf16": OUT_NHWC4_PAD_BF16, "fp16": OUT_NHWC4_PAD_FP16, "u8": OUT_U8_HWC}
 
 
+def _alloc_shape(n: int, fmt: str):
+    return {"nchw_f32": (n, 3, PATCH, PATCH), "u8": (n, PATCH, PATCH, 3)}.get(fmt, (n, PAD_H, PAD_W, 4))
+
+
+def _alloc_dtype(fmt: str):
+    return {"nchw_f32": torch.float32, "u8": torch.uint8, "bf16": torch.bfloat16}.get(fmt, torch.float16)
+
+
 def _alloc_out(n: int, fmt: str, device) -> torch.Tensor:
-    if fmt == "nchw_f32":
-        return torch.empty((n, 3, PATCH, PATCH), dtype=torch.float32, device=device)
-    if fmt == "u8":
-        return torch.empty((n, PATCH, PATCH, 3), dtype=torch.uint8, device=device)
-    return torch.empty((n, PAD_H, PAD_W, 4), dtype=torch.bfloat16 if fmt == "bf16" else torch.float16, device=device)
+    return torch.empty(_alloc_shape(n, fmt), dtype=_alloc_dtype(fmt), device=device)
 
 
 def tile_preprocess(
@@ -492,13 +527,17 @@ def window_labels_cells(cellany: torch.Tensor, W: int, H: int, xy: torch.Tensor,
     return labels
 
 
-def patches_normalize(patches: torch.Tensor, out_format: str = "nchw_f32") -> torch.Tensor:
-    """uint8[n,224,224,3] on cuda -> network input (ToTensor + Normalize)."""
+def patches_normalize(patches: torch.Tensor, out_format: str = "nchw_f32", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8[n,224,224,3] on cuda -> network input (ToTensor + Normalize); ``out``: write into this tensor."""
     _require_gpu(patches)
     if patches.dtype != torch.uint8 or tuple(patches.shape[1:]) != (PATCH, PATCH, 3):
         raise HipacError("patches must be uint8[n,224,224,3]")
     n = patches.shape[0]
-    out = _alloc_out(n, out_format, patches.device)
+    if out is None:
+        out = _alloc_out(n, out_format, patches.device)
+    elif not out.is_contiguous() or out.device != patches.device or out.shape != _alloc_shape(n, out_format) or \
+            out.dtype != _alloc_dtype(out_format):
+        raise HipacError("patches_normalize: out has the wrong shape / dtype / device")
     if n == 0:
         return out
     lut = device_lut(patches.device)

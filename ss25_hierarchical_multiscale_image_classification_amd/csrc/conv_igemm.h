@@ -2018,6 +2018,18 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
   *reinterpret_cast<frag*>(out + (((size_t)b * HO + oh) * WO + ow) * C + c8 * 8) = o;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device)
+constexpr int kMaxDevices = 64;
+static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+  if (dev >= 0 && done[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0) done[dev] = true;
+  return 0;
+}
+
 #ifndef HIPAC_HALO_BM256
 #define HIPAC_HALO_BM256 1
 #endif
@@ -2075,12 +2087,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int STG = 4 * 32 * (BN / 2 * 4 + 16);  // epilogue staging, aliases the ring
     constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
     auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return (int)e;
-      attr_done = true;
-    }
+    static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
+    if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
     const int mt8 = (n_mtiles + 7) / 8 * 8;
     const int n_vtiles = mt8 * (COUT / BN);
@@ -2093,12 +2101,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
     constexpr int LDS = NSTAGE * (BM + BN) * 128;
     auto kern = conv_glds_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BM, BN, NSTAGE, RELU, RESID, OUTF32>;
-    static bool attr_done = false;  // idempotent; a benign race at worst repeats the call
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return (int)e;
-      attr_done = true;
-    }
+    static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
+    if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
     const int mt8 = (n_mtiles + 7) / 8 * 8;
     dim3 grid(mt8 * (COUT / BN));
@@ -2137,12 +2141,8 @@ static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* ou
   constexpr int HO = HI / 2;
   const int M = n * HO * HO;
   auto kern = conv_glds_kernel<T, CIN, COUT, HI, HI, 3, 2, BM, BN, NSTAGE, true, false, false, true>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static bool attr_done[kMaxDevices] = {};
+  if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
   const int n_mtiles = (M + BM - 1) / BM;
   const int mt8 = (n_mtiles + 7) / 8 * 8;
   dim3 grid(mt8 * (COUT / BN));

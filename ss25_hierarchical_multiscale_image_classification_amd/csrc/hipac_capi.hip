@@ -326,6 +326,7 @@ struct hipac_weights {
   // and one here, so the tail of every launch (partly filled last round of workgroups) is
   // covered by the other lane's kernels.  Fork / join with the caller's stream by events.
   hipStream_t lane_stream = nullptr;
+  int device = 0;  // the device that was current at pack time: weights, lane stream and kernel attributes live there
 };
 
 // Split of one forward call into lanes.  Each lane owns a whole workspace plan.
@@ -381,6 +382,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
                 "pack: fc_w / num_classes mismatch");
   hipac_weights_t* w = new hipac_weights_t();
   memset(&w->net, 0, sizeof(Net));
+  HIPAC_CHECK_HIP(hipGetDevice(&w->device));
   w->net.precision = precision;
   w->net.num_classes = params->num_classes;
   const float eps = params->bn_eps;
@@ -445,6 +447,12 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
                 "forward: logits/labels requested but the weights carry no fc (fc = Identity)");
   HIPAC_REQUIRE(((uintptr_t)workspace & 255) == 0, HIPAC_EINVAL, "forward: workspace must be 256-byte aligned");
   HIPAC_REQUIRE(((uintptr_t)x & 15) == 0, HIPAC_EINVAL, "forward: x must be 16-byte aligned");
+  {
+    int dev = -1;
+    HIPAC_CHECK_HIP(hipGetDevice(&dev));
+    HIPAC_REQUIRE(dev == w->device, HIPAC_EINVAL, "forward: handle was packed on device %d, current device is %d",
+                  w->device, dev);
+  }
   const Lanes L = make_lanes(batch, w->net.precision);
   Plan p = L.p;
   HIPAC_REQUIRE(workspace_bytes >= L.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",

@@ -449,8 +449,11 @@ int hipac_level_gather(const void* dimg, int W, int H, int P, const int32_t* xy,
   HIPAC_REQUIRE(dimg && xy && out && n >= 0, HIPAC_EINVAL, "level_gather: bad argument");
   if (n == 0) return 0;
   const PlaneGeom g = make_geom(W, H, P);
-  hipLaunchKernelGGL(gather_kernel, dim3(kLat / 8, n), dim3(256), 0, (hipStream_t)stream, (const unsigned*)dimg, g,
-                     xy, out);
+  for (int w0 = 0; w0 < n; w0 += 65535) {  // gridDim.y limit
+    const int nw = n - w0 < 65535 ? n - w0 : 65535;
+    hipLaunchKernelGGL(gather_kernel, dim3(kLat / 8, nw), dim3(256), 0, (hipStream_t)stream, (const unsigned*)dimg, g,
+                       xy + 2 * (size_t)w0, out + (size_t)w0 * kLat * kLat * 3);
+  }
   HIPAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -258,6 +258,8 @@ static double triangle(double x) {
 
 using namespace hipac;
 
+constexpr int kMaxGridY = 65535;  // HIP limit of gridDim.y
+
 extern "C" {
 
 // Pillow: precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for the
@@ -334,33 +336,39 @@ int hipac_tile_preprocess(const uint8_t* level, int W, int H, int64_t pitch, int
   if (sums) HIPAC_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)n * 4, s));
   if (out_format == HIPAC_OUT_NHWC4_PAD_BF16 || out_format == HIPAC_OUT_NHWC4_PAD_FP16)
     HIPAC_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n * out_bytes_per_patch(out_format), s));
-  dim3 grid(kStrips, n);
-  if (P == kPatch) {
-    if (chans == 3)
-      hipLaunchKernelGGL((tile_identity_kernel<3>), grid, dim3(256), 0, s, level, W, H, (long long)pitch, 0LL, xy,
-                         lut, out, out_format, sums);
-    else
-      hipLaunchKernelGGL((tile_identity_kernel<4>), grid, dim3(256), 0, s, level, W, H, (long long)pitch, 0LL, xy,
-                         lut, out, out_format, sums);
-  } else {
+  // gridDim.y is limited to 65 535: windows go in chunks (pointers advanced per chunk, kernels index from 0)
+  const size_t obytes = out_bytes_per_patch(out_format);
+  const int maxrows = P == kPatch ? 0 : (kStripRows + 1) * (P / kPatch);
+  const size_t lds = P == kPatch ? 0 : (size_t)kPatch * ksize * 4 + (size_t)maxrows * kPatch * 3 + (size_t)4 * P * chans;
+  if (P != kPatch) {
     HIPAC_REQUIRE(coeff_bounds && coeff_kk, HIPAC_EINVAL, "tile_preprocess: coefficient tables are null");
     const int scale = P / kPatch;
     HIPAC_REQUIRE(ksize == 2 * scale + 1, HIPAC_EINVAL, "tile_preprocess: ksize %d != %d", ksize, 2 * scale + 1);
     HIPAC_REQUIRE(pitch % 16 == 0 && ((uintptr_t)level & 15) == 0, HIPAC_EINVAL,
                   "tile_preprocess: level base and pitch must be 16-byte aligned");
-    const int maxrows = (kStripRows + 1) * scale;
-    const size_t lds = (size_t)kPatch * ksize * 4 + (size_t)maxrows * kPatch * 3 + (size_t)4 * P * chans;
     HIPAC_REQUIRE(lds <= 160 * 1024, HIPAC_EUNSUPPORTED, "tile_preprocess: LDS %zu", lds);
-    if (chans == 3) {
-      HIPAC_CHECK_HIP(hipFuncSetAttribute((const void*)tile_resize_kernel<3>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((tile_resize_kernel<3>), grid, dim3(256), lds, s, level, W, H, (long long)pitch, xy, P,
-                         coeff_bounds, coeff_kk, ksize, lut, out, out_format, sums, maxrows);
+    HIPAC_CHECK_HIP(hipFuncSetAttribute(chans == 3 ? (const void*)tile_resize_kernel<3> : (const void*)tile_resize_kernel<4>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  for (int w0 = 0; w0 < n; w0 += kMaxGridY) {
+    const int nw = n - w0 < kMaxGridY ? n - w0 : kMaxGridY;
+    dim3 grid(kStrips, nw);
+    const int32_t* xyc = xy + 2 * (size_t)w0;
+    void* outc = (char*)out + (size_t)w0 * obytes;
+    uint32_t* sumc = sums ? sums + w0 : nullptr;
+    if (P == kPatch) {
+      if (chans == 3)
+        hipLaunchKernelGGL((tile_identity_kernel<3>), grid, dim3(256), 0, s, level, W, H, (long long)pitch, 0LL, xyc,
+                           lut, outc, out_format, sumc);
+      else
+        hipLaunchKernelGGL((tile_identity_kernel<4>), grid, dim3(256), 0, s, level, W, H, (long long)pitch, 0LL, xyc,
+                           lut, outc, out_format, sumc);
+    } else if (chans == 3) {
+      hipLaunchKernelGGL((tile_resize_kernel<3>), grid, dim3(256), lds, s, level, W, H, (long long)pitch, xyc, P,
+                         coeff_bounds, coeff_kk, ksize, lut, outc, out_format, sumc, maxrows);
     } else {
-      HIPAC_CHECK_HIP(hipFuncSetAttribute((const void*)tile_resize_kernel<4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((tile_resize_kernel<4>), grid, dim3(256), lds, s, level, W, H, (long long)pitch, xy, P,
-                         coeff_bounds, coeff_kk, ksize, lut, out, out_format, sums, maxrows);
+      hipLaunchKernelGGL((tile_resize_kernel<4>), grid, dim3(256), lds, s, level, W, H, (long long)pitch, xyc, P,
+                         coeff_bounds, coeff_kk, ksize, lut, outc, out_format, sumc, maxrows);
     }
   }
   HIPAC_CHECK_HIP(hipGetLastError());
@@ -392,9 +400,14 @@ int hipac_patches_normalize(const uint8_t* patches, int n, const float* lut, voi
   hipStream_t s = (hipStream_t)stream;
   if (out_format != HIPAC_OUT_NCHW_F32)
     HIPAC_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n * out_bytes_per_patch(out_format), s));
-  hipLaunchKernelGGL((tile_identity_kernel<3>), dim3(kStrips, n), dim3(256), 0, s, patches, kPatch, kPatch,
-                     (long long)kPatch * 3, (long long)kPatch * kPatch * 3, (const int*)nullptr, lut, out,
-                     out_format, (unsigned*)nullptr);
+  const size_t obytes = out_bytes_per_patch(out_format);
+  for (int w0 = 0; w0 < n; w0 += kMaxGridY) {
+    const int nw = n - w0 < kMaxGridY ? n - w0 : kMaxGridY;
+    hipLaunchKernelGGL((tile_identity_kernel<3>), dim3(kStrips, nw), dim3(256), 0, s,
+                       patches + (size_t)w0 * kPatch * kPatch * 3, kPatch, kPatch, (long long)kPatch * 3,
+                       (long long)kPatch * kPatch * 3, (const int*)nullptr, lut, (char*)out + (size_t)w0 * obytes,
+                       out_format, (unsigned*)nullptr);
+  }
   HIPAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

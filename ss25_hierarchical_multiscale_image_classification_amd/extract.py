@@ -220,6 +220,8 @@ class LevelWindows:
     order): window origins, whiteness sums, keep flags, tumour labels -- plus the resized
     uint8 pixels of any subset of windows on demand."""
 
+    CHUNK = 8192  # windows per launch of the per-window kernel (non-lattice grids)
+
     def __init__(self, slide: DeviceSlide, level: int, stride: Optional[int] = None, pad: bool = True,
                  use_planes: Optional[bool] = None):
         self.level = level
@@ -233,11 +235,27 @@ class LevelWindows:
         self.planes = capi.LevelPlanes(self.img, self.P, width=width) if (can_planes and use_planes is not False) else None
         if use_planes and not can_planes:
             raise capi.HipacError("planes path needs P in (448, 896, 1792) and a stride multiple of 224")
-        self._all_u8 = None
+        self._kept_u8, self._kept_pos = None, None
         if self.planes is not None:
             self.sums, self.keep = self.planes.stats(self.xy)
         else:
-            self._all_u8, self.sums, self.keep = capi.tile_preprocess(self.img, self.xy, self.P, "u8", width=width)
+            # any other window list: per-window kernel, in chunks, keeping only the pixels of kept windows (a level
+            # scanned with a small stride has hundreds of thousands of windows: 150 KB each for all of them, dropped
+            # ones included, would be tens of GB)
+            n = self.xy.shape[0]
+            sums, keeps, pix = [], [], []
+            for i0 in range(0, n, self.CHUNK):
+                o, sm, kp = capi.tile_preprocess(self.img, self.xy[i0:i0 + self.CHUNK].contiguous(), self.P, "u8", width=width)
+                sums.append(sm), keeps.append(kp)
+                pix.append(o.index_select(0, torch.nonzero(kp, as_tuple=False).flatten()))
+            if n:
+                self.sums, self.keep = torch.cat(sums), torch.cat(keeps)
+                self._kept_u8 = torch.cat(pix)
+            else:
+                self.sums = torch.empty((0,), dtype=torch.int32, device=slide.device)
+                self.keep = torch.empty((0,), dtype=torch.uint8, device=slide.device)
+                self._kept_u8 = torch.empty((0, 224, 224, 3), dtype=torch.uint8, device=slide.device)
+            self._kept_pos = torch.cumsum(self.keep.to(torch.int64), 0) - 1  # window index -> row of _kept_u8
         mask = slide.mask(level)
         if mask is None:
             self.labels = torch.zeros((self.xy.shape[0],), dtype=torch.uint8, device=slide.device)
@@ -250,11 +268,12 @@ class LevelWindows:
         return torch.nonzero(self.keep, as_tuple=False).flatten()
 
     def patches(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """uint8[len(idx),224,224,3] resized pixels of the selected windows (into ``out`` if given)."""
-        if self._all_u8 is not None:
+        """uint8[len(idx),224,224,3] resized pixels of the selected KEPT windows (into ``out`` if given)."""
+        if self._kept_u8 is not None:
+            rows = self._kept_pos.index_select(0, idx)
             if out is None:
-                return self._all_u8.index_select(0, idx)
-            torch.index_select(self._all_u8, 0, idx, out=out)
+                return self._kept_u8.index_select(0, rows)
+            torch.index_select(self._kept_u8, 0, rows, out=out)
             return out
         return self.planes.gather(self.xy.index_select(0, idx), out=out)
 
@@ -286,17 +305,17 @@ class WSIPatchStream:
 
 @torch.no_grad()
 def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[int] = (0, 1, 2, 3),
-                batch_windows: int = 4096, stride=None, want_logits: bool = True):
+                batch_windows: int = 4096, stride=None, want_logits: bool = True, fwd_batch: int = 8192):
     """Whole-slide hierarchical scan: windows -> whiteness/labels -> resize -> ResNet18 ->
     per-patch features / logits / labels.  The kept windows of ALL requested levels are scored
     in large batches (the late ResNet layers need thousands of patches per launch to fill the
-    chip).  ``stride``: None (reference: 224), an int, or a callable level -> stride.
+    chip; ``fwd_batch`` patches per forward).  ``stride``: None (reference: 224), an int, or a callable level -> stride.
     Returns device tensors (feats[n,512], logits[n,C] or None, pred int64[n] or None,
     meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order."""
     has_fc = net.num_classes > 0 and want_logits
     dev = slide.device
     levels = list(levels)
-    FWD = 8192  # patches per forward: the late layers need thousands of patches per launch
+    FWD = max(1, int(fwd_batch))  # patches per forward: the late layers need thousands of patches per launch
 
     def stride_of(level):
         return stride(level) if callable(stride) else stride

@@ -232,21 +232,48 @@ class TiffPyramid:
         return out
 
 
+def _split_jpeg_tables(data: bytes) -> Tuple[bytes, bytes]:
+    """A complete baseline JPEG -> (tables-only stream SOI DQT.. DHT.. EOI, abbreviated image stream without
+    DQT / DHT): the two halves of TIFF's JPEGTables (tag 347) scheme, the form CAMELYON16's files use."""
+    if data[:2] != b"\xff\xd8":
+        raise TiffError("not a JPEG stream")
+    pos, tables, rest = 2, b"", b""
+    while True:
+        if data[pos] != 0xFF:
+            raise TiffError("JPEG marker expected")
+        m = data[pos + 1]
+        if m == 0xDA:  # start of scan: the entropy-coded data and EOI follow
+            rest += data[pos:]
+            break
+        length = int.from_bytes(data[pos + 2:pos + 4], "big")
+        seg = data[pos:pos + 2 + length]
+        if m in (0xDB, 0xC4):
+            tables += seg
+        else:
+            rest += seg
+        pos += 2 + length
+    return b"\xff\xd8" + tables + b"\xff\xd9", b"\xff\xd8" + rest
+
+
 def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, compression: str = "jpeg",
-                     quality: int = 90, bigtiff: bool = False, missing: Sequence[Tuple[int, int, int]] = ()):
+                     quality: int = 90, bigtiff: bool = False, missing: Sequence[Tuple[int, int, int]] = (),
+                     jpeg_tables: bool = False):
     """Minimal writer of a tiled pyramid (tests and synthetic data only): ``levels`` are uint8[H,W,3]
-    arrays, largest first.  compression: "none" | "deflate" | "jpeg" (YCbCr, abbreviated tables are not
-    used: every tile is a complete JPEG).  ``missing``: (level, ty, tx) tiles written with byte count 0."""
+    arrays, largest first.  compression: "none" | "deflate" | "jpeg" (YCbCr; every tile a complete JPEG, or with
+    ``jpeg_tables=True`` abbreviated streams plus one JPEGTables tag per directory, as real slide files have
+    them).  ``missing``: (level, ty, tx) tiles written with byte count 0."""
     from PIL import Image
 
     comp = {"none": 1, "deflate": 8, "jpeg": 7}[compression]
     bo = "<"
     blobs, ifd_specs = [], []
     pos = 16 if bigtiff else 8
+    tables_of_level = []
     for li, img in enumerate(levels):
         h, w = img.shape[:2]
         ta, td = (w + tile - 1) // tile, (h + tile - 1) // tile
         offs, cnts = [], []
+        level_tables = None
         for ty in range(td):
             for tx in range(ta):
                 if (li, ty, tx) in missing:
@@ -263,10 +290,16 @@ def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, c
                     bio = io.BytesIO()
                     Image.fromarray(t, "RGB").save(bio, "JPEG", quality=quality)
                     data = bio.getvalue()
+                    if jpeg_tables:  # fixed quality, default Huffman tables: every tile shares one set
+                        tb, data = _split_jpeg_tables(data)
+                        if level_tables is not None and tb != level_tables:
+                            raise TiffError("tiles of one level do not share their JPEG tables")
+                        level_tables = tb
                 offs.append(pos), cnts.append(len(data))
                 blobs.append(data)
                 pos += len(data)
         ifd_specs.append((w, h, ta * td, offs, cnts))
+        tables_of_level.append(level_tables)
     out = bytearray()
     # data area first, then IFDs (offsets known up front)
     body = b"".join(blobs)
@@ -278,6 +311,8 @@ def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, c
         entries = [(254, 4, [1 if li else 0]), (256, 4, [w]), (257, 4, [h]), (258, 3, [8, 8, 8]), (259, 3, [comp]),
                    (262, 3, [photometric]), (277, 3, [3]), (284, 3, [1]), (322, 4, [tile]), (323, 4, [tile]),
                    (324, 16 if bigtiff else 4, offs), (325, 16 if bigtiff else 4, cnts)]
+        if tables_of_level[li] is not None:
+            entries.append((347, 7, list(tables_of_level[li])))  # JPEGTables (UNDEFINED bytes); tags stay sorted
         n = len(entries)
         esz, cw = (20, 8) if bigtiff else (12, 4)
         head = 8 if bigtiff else 2

@@ -30,9 +30,9 @@ def test_score_slide_matches_oracle_pipeline():
     assert np.array_equal(meta.cpu().numpy(), np.array(rows, np.int32))  # same windows, same order
     ref_f, ref_l = R.resnet18_forward(torch.stack(ref_x), sd)
     rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
-    assert rel(feats, ref_f) <= 2.5e-3 and rel(logits, ref_l) <= 2.5e-3
+    assert rel(feats, ref_f) <= 1e-3 and rel(logits, ref_l) <= 2e-3  # fp16: features at north_star's bound
     margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
-    decided = margin > 2 * 2.5e-3 * ref_l.abs().max()
+    decided = margin > 2 * 2e-3 * ref_l.abs().max()
     assert torch.equal(preds.cpu()[decided], ref_l.argmax(1)[decided])
     # the fused feature-extraction entry point names patches like the reference (main.py:722)
     f3, lab3, paths = features.extract_features_from_slide(slide, net, 3)
@@ -40,6 +40,78 @@ def test_score_slide_matches_oracle_pipeline():
     assert f3.shape == (n3, 512) and len(paths) == n3 and lab3.dtype == np.int64
     first = next(r for r in rows if r[0] == 3)
     assert paths[0] == f"tumor_901/tumor_901_x{first[1]}_y{first[2]}_{'tumor' if first[3] else 'normal'}.png"
+
+
+def _oracle_rows(levels_np, polys, sd, levels):
+    ref_slide = E.ArraySlide(levels_np)
+    rows, ref_x = [], []
+    for level in levels:
+        wins, pix = E.extract_patches_ref(ref_slide, level, polygons_l0=polys)
+        for w, p in zip([w for w in wins if w.keep], pix):
+            rows.append((level, w.x, w.y, w.label))
+            ref_x.append(torch.from_numpy(T.eval_transform(p)))
+    ref_f, ref_l = R.resnet18_forward(torch.stack(ref_x), sd)
+    return np.array(rows, np.int32), ref_f, ref_l
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2.5e-2)])
+def test_score_slide_all_levels_matches_oracle(prec, tol):
+    """BASELINE configs[2] end to end, level 0 included (`--patch_level all`, src/main.py:1120-1122): a slide with
+    ragged right / bottom edges (level-0 windows of 1792 px clipped at both borders, 132 of them on the stride-224
+    grid), windows / order / labels identical to the oracle's extractor, features and logits within the
+    precision's tolerance.  Level 0 is the BIG level of score_slide's schedule: its windows are decided and
+    gathered on the side stream under the forwards of levels 1-3 and the results are permuted back into
+    level-major order -- this is the check of that reorder logic (small forward batches force several
+    forwards per level)."""
+    W, H, seed = 2600, 2300, 5
+    levels = synth.build_pyramid(synth.synth_level0(W, H, seed=seed, n_blobs=4), 4)
+    polys = synth.synth_polygons(W, H, seed=seed)
+    slide = extract.DeviceSlide(levels, device="cuda", name="tumor_902")
+    slide.polygons = polys
+    sd = synth.seeded_resnet18_state_dict(5, num_classes=2)
+    rows, ref_f, ref_l = _oracle_rows([l.numpy() for l in levels], polys, sd, (0, 1, 2, 3))
+    assert (rows[:, 0] == 0).sum() >= 40  # level 0 really contributes
+    net = capi.PackedResNet18(sd, precision=prec)
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+    for kw in (dict(), dict(batch_windows=13, fwd_batch=32)):
+        feats, logits, preds, meta = extract.score_slide(slide, net, levels=(0, 1, 2, 3), **kw)
+        torch.cuda.synchronize()
+        assert np.array_equal(meta.cpu().numpy(), rows)  # same windows, same labels, reference order
+        assert rel(feats, ref_f) <= tol and rel(logits, ref_l) <= tol, (prec, kw)
+        margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
+        decided = margin > 2 * tol * ref_l.abs().max()
+        assert torch.equal(preds.cpu()[decided], ref_l.argmax(1)[decided])
+    # listing order of the levels is the output order, whatever the processing order
+    f2, l2, _, m2 = extract.score_slide(slide, net, levels=(2, 0), fwd_batch=32)
+    sel = np.concatenate([np.nonzero(rows[:, 0] == 2)[0], np.nonzero(rows[:, 0] == 0)[0]])
+    assert np.array_equal(m2.cpu().numpy(), rows[sel])
+    assert rel(f2, ref_f[sel]) <= tol
+
+
+def test_score_slide_non_lattice_stride_uses_the_per_window_kernel():
+    """A stride that is not a multiple of 224 leaves the whole-level resampler: windows go through the per-window
+    kernel in chunks and only kept windows keep their pixels; decisions and features equal the oracle's."""
+    W, H, seed = 1500, 1250, 9
+    levels = synth.build_pyramid(synth.synth_level0(W, H, seed=seed, n_blobs=3), 4)
+    slide = extract.DeviceSlide(levels, device="cuda", name="normal_11")
+    sd = synth.seeded_resnet18_state_dict(6, num_classes=2)
+    net = capi.PackedResNet18(sd, precision="fp32")
+    old = extract.LevelWindows.CHUNK
+    extract.LevelWindows.CHUNK = 7  # several chunks
+    try:
+        feats, logits, _, meta = extract.score_slide(slide, net, levels=(1, 2), stride=160)
+    finally:
+        extract.LevelWindows.CHUNK = old
+    ref_slide = E.ArraySlide([l.numpy() for l in levels])
+    rows, ref_x = [], []
+    for level in (1, 2):
+        wins, pix = E.extract_patches_ref(ref_slide, level, stride=160)
+        for w, p in zip([w for w in wins if w.keep], pix):
+            rows.append((level, w.x, w.y, w.label))
+            ref_x.append(torch.from_numpy(T.eval_transform(p)))
+    assert np.array_equal(meta.cpu().numpy(), np.array(rows, np.int32))
+    ref_f, _ = R.resnet18_forward(torch.stack(ref_x), sd)
+    assert float((feats.cpu() - ref_f).abs().max() / ref_f.abs().max()) <= 2e-5
 
 
 def test_png_tree_flow_equals_fused_flow(tmp_path):

@@ -2,15 +2,19 @@
 committed golden vectors.
 
 Tolerances (norm-relative: max|a-b| / max|b| per tensor), with the values measured on
-MI355X in round 1 in brackets -- the arithmetic is fp32-accumulated MFMA on operands
-rounded to the named type, so the error is rounding only and grows ~sqrt(depth):
+MI355X in brackets -- the arithmetic is fp32-accumulated MFMA on operands rounded to the
+named type, so the error is rounding only:
     fp32 : features 2e-5   logits 2e-5   taps 2e-5   (parity mode: fp32 storage, exact f32 MFMA; the
            only differences from the oracle are BN folding and summation order)
-    fp16 : features 2.5e-3 [5e-4]   logits 2.5e-3 [9e-4]   intermediate taps 3e-3 [<=1.3e-3]
-    bf16 : features 2.5e-2 [4e-3]   logits 2.5e-2 [7e-3]   intermediate taps 3e-2 [<=1.0e-2]
-north_star's 1e-3 (fp32-relative) is met with two orders of magnitude to spare by the fp32
-mode and, on features, by the fp16 mode; bf16 (the BASELINE dtype, the one benchmarked) cannot
-meet it by construction (8-bit mantissa, 20 roundings deep) -- see DESIGN.md.
+    fp16 : features 1e-3 [4-6e-4]   logits 2e-3 [0.8-1.3e-3]   intermediate taps 3e-3 [<=1.3e-3]
+    bf16 : features 2.5e-2 [4e-3]   logits 2.5e-2 [7e-3 - 1.3e-2]   intermediate taps 3e-2 [<=1.0e-2]
+north_star's 1e-3 (fp32-relative) is met with three orders of magnitude to spare by the fp32
+mode and ENFORCED here for the fp16 features.  The fp16 LOGITS sit at the bound (0.8-1.3e-3 depending on
+the patch set): the fc output cancels (|logit| << sum |w_i f_i|), so the same absolute feature error is
+a ~2x larger relative logit error.  tools/prec_sites.py shows why no 16-bit operand format does better at
+full MFMA rate: each of the ~40 rounding sites (20 weight tensors, 20 activation tensors) alone moves the
+logits by 1.5-4e-4 and they add in quadrature; an fp32 residual stream removes 8 half-sites (-5 %).
+bf16 (the BASELINE dtype, the one benchmarked) cannot meet 1e-3 by construction (8-bit mantissa).
 Labels must be identical wherever the oracle's margin |l0-l1| exceeds twice the
 logit error bound; near-ties are counted and reported, not hidden.
 """
@@ -22,7 +26,8 @@ from oracle import resnet18_ref as R, transform_ref as T
 from ss25_hierarchical_multiscale_image_classification_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp16": dict(out=2.5e-3, tap=3e-3), "bf16": dict(out=2.5e-2, tap=3e-2), "fp32": dict(out=2e-5, tap=2e-5)}
+TOL = {"fp16": dict(feat=1e-3, out=2e-3, tap=3e-3), "bf16": dict(feat=2.5e-2, out=2.5e-2, tap=3e-2),
+       "fp32": dict(feat=2e-5, out=2e-5, tap=2e-5)}  # "out" bounds the logits, "feat" the 512-d features
 TAPS = ["stem", "maxpool"] + [f"layer{s}.{k}" for s in (1, 2, 3, 4) for k in (0, 1)]
 
 
@@ -51,7 +56,7 @@ def test_golden_features_logits_labels(golden, prec, seed):
     net = capi.PackedResNet18(golden_sd(golden, seed), precision=prec)
     f, l, lab = net.forward(x, want_feats=True, want_logits=True, want_labels=True)
     ref_f, ref_l = golden[f"s{seed}_feats"], golden[f"s{seed}_logits"]
-    assert rel(f, ref_f) <= TOL[prec]["out"]
+    assert rel(f, ref_f) <= TOL[prec]["feat"]
     assert rel(l, ref_l) <= TOL[prec]["out"]
     bound = 2 * TOL[prec]["out"] * float(np.abs(ref_l).max())
     margin = np.abs(ref_l[:, 0] - ref_l[:, 1])
@@ -77,7 +82,7 @@ def test_full_taps_against_oracle_random_patches(prec):
     ref_f, ref_l = R.resnet18_forward(x, sd, taps)
     net = capi.PackedResNet18(sd, precision=prec)
     f, l, _ = net.forward(x.cuda(), want_feats=True, want_logits=True)
-    assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
+    assert rel(f, ref_f) <= TOL[prec]["feat"] and rel(l, ref_l) <= TOL[prec]["out"]
     for i, name in enumerate(TAPS):
         if i == 0 and prec != "fp32":
             with pytest.raises(capi.HipacError):
@@ -154,12 +159,12 @@ def test_uint8_strip_kernel_against_oracle(prec):
     net = capi.PackedResNet18(sd, precision=prec)
     f, l, _ = net.forward(u8.cuda(), want_logits=True)
     assert rel(net.tap(7, 1), taps["maxpool"]) <= TOL[prec]["tap"]
-    assert rel(f, ref_f) <= TOL[prec]["out"] and rel(l, ref_l) <= TOL[prec]["out"]
+    assert rel(f, ref_f) <= TOL[prec]["feat"] and rel(l, ref_l) <= TOL[prec]["out"]
     big = synth.synth_patches_u8(300, seed=5)  # 600 strips: workgroups walk more than one strip
     xb = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in big[[0, 150, 299]]])
     ref_fb, _ = R.resnet18_forward(xb, sd)
     fb, _, _ = net.forward(big.cuda(), want_logits=True)
-    assert rel(fb[[0, 150, 299]], ref_fb) <= TOL[prec]["out"]
+    assert rel(fb[[0, 150, 299]], ref_fb) <= TOL[prec]["feat"]
 
 
 def test_sub_batching_and_determinism(monkeypatch):
@@ -259,7 +264,7 @@ def test_reference_class_surface_on_gpu():
     uni = UnifiedResNet(classifier=False).set_precision("fp16")
     load_into(uni, to_layout(bare, "simclr"), drop_fc=True)
     with torch.no_grad():
-        assert rel(uni.cuda().eval()(x.cuda()), ref_f) <= TOL["fp16"]["out"]
+        assert rel(uni.cuda().eval()(x.cuda()), ref_f) <= TOL["fp16"]["feat"]
     with pytest.raises(capi.HipacError):
         uni(x)  # eval-mode CPU tensor: no CPU fallback
 
@@ -278,6 +283,32 @@ def test_fp32_parity_mode_meets_1e3_with_margin_and_labels_exactly():
     assert elem < 1e-3  # element-wise relative, not just norm-relative
     margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
     assert torch.equal(lab.cpu()[margin > 1e-5], ref_l.argmax(1)[margin > 1e-5])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_configs0_256_patches_against_oracle(prec):
+    """BASELINE configs[0] / SURVEY 8(d): 256 seeded random 224x224x3 patches, seeded state_dict #0, uint8 input
+    (the benchmarked entry form).  fp32: features and logits within 1e-3 (measured ~1e-6) and every label identical
+    outside exact near-ties.  fp16: features within 1e-3 (enforced), logits within 2e-3.  bf16: 2.5e-2.
+    Labels of the 16-bit modes must match wherever the oracle margin exceeds twice the measured logit error."""
+    sd = synth.seeded_resnet18_state_dict(0, num_classes=2)
+    u8 = synth.synth_patches_u8(256, seed=1)
+    lut = torch.from_numpy(T.normalize_lut())
+    x = torch.stack([lut[c][u8[..., c].long()] for c in range(3)], dim=1)
+    ref_f, ref_l = R.resnet18_forward(x, sd)
+    net = capi.PackedResNet18(sd, precision=prec)
+    f, l, lab = net.forward(u8.cuda(), want_feats=True, want_logits=True, want_labels=True)
+    ef, el = rel(f, ref_f), rel(l, ref_l)
+    print(f"configs[0] {prec}: features {ef:.2e} logits {el:.2e}")
+    if prec == "fp32":
+        assert ef <= 1e-3 and el <= 1e-3 and ef <= 2e-5 and el <= 2e-5
+    else:
+        assert ef <= TOL[prec]["feat"] and el <= TOL[prec]["out"]
+    margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
+    decided = margin > 2 * float((l.cpu() - ref_l).abs().max())
+    assert int(decided.sum()) >= 200
+    assert torch.equal(lab.cpu()[decided], ref_l.argmax(1)[decided])
+    assert torch.equal(lab, l.argmax(1))
 
 
 @pytest.mark.parametrize("n", [2047, 2049, 4099])

@@ -1,0 +1,184 @@
+"""Native training step (csrc/train.hip through the C ABI) against the autograd oracle (torch-CPU fp32,
+oracle/train_ref.py): every parameter gradient of a train-mode step, the loss, the updated running statistics.
+
+The oracle is given the ACTIVATION PATTERN of the run under test (which ReLU units are on, which element won
+each max-pool window; oracle/train_ref.py::_ReluGiven): a ReLU's derivative is discontinuous at 0, two fp32
+implementations disagree on a handful of the ~10 M units of a step, and each disagreement moves the heavily
+cancelling gradient sums by percents (torch's own fp32 and fp64 runs differ by 1e-2 on layer1-3 gradients for
+that reason).  The oracle's VALUES stay its own; the test also bounds how many units disagree.
+
+Tolerances (norm-relative per tensor, max|a-b| / max|b|): fp32 on both sides (exact f32 MFMA here, fp32 FMA on
+the CPU), so what remains is summation order through 20 train-mode batch-norms and their backward passes:
+    loss 1e-5, every gradient tensor 5e-4 [measured: <= 5e-5], running statistics 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_ref as TR
+from ss25_hierarchical_multiscale_image_classification_amd import capi, train_native as TN
+from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier
+from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 5e-4
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+            m.running_mean.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+            m.running_var.data = 0.5 + torch.rand(m.bias.shape, generator=g)
+
+
+def patterns(enc, slot, hidden=None):
+    """Activation pattern of the forward in workspace ``slot`` (and the projector's hidden layer), keyed like the
+    oracle's taps."""
+    m = {"pool_idx": enc.tap(slot, "pool_idx", 0).cpu()}
+    for i, e in enumerate(enc.table):
+        if "downsample" not in e["conv"]:
+            m[e["conv"] + ".post"] = enc.tap(slot, "post", i).cpu() > 0
+    if hidden is not None:
+        m["projector.hidden"] = hidden.cpu() > 0
+    return m
+
+
+def count_disagreements(sd_bare, x, masks):
+    """How many ReLU units the oracle's own forward would switch differently (bounded, reported)."""
+    p, st = TR._split(sd_bare)
+    taps = {}
+    with torch.no_grad():
+        TR.encoder_train_forward(x, p, st, taps)
+    return sum(int(((taps[k] > 0) != v).sum()) for k, v in masks.items() if k in taps and k != "pool_idx")
+
+
+def test_linear_cross_entropy_adam_against_torch():
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    for (M, N, K, relu) in ((16, 512, 512, True), (16, 128, 512, False), (37, 2, 512, False), (130, 70, 33, True)):
+        flat = TN.FlatAdam(TN.NativeLinear.floats(N, K), dev, 1e-3)
+        lin = TN.NativeLinear(flat, 0, N, K, relu=relu)
+        w, b, x = torch.randn(N, K) * 0.05, torch.randn(N) * 0.1, torch.randn(M, K)
+        lin.w.copy_(w), lin.b.copy_(b)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = torch.nn.functional.linear(xr, wr, br)
+        yr = torch.relu(yr) if relu else yr
+        dy = torch.randn(M, N)
+        yr.backward(dy)
+        xd = x.to(dev)
+        y = lin.forward(xd)
+        dx = lin.backward(xd, y, dy.to(dev), accumulate=False)
+        assert rel(y, yr.detach()) < 1e-5 and rel(dx, xr.grad) < 1e-5
+        assert rel(lin.dw, wr.grad) < 1e-5 and rel(lin.db, br.grad) < 1e-5
+        lin.backward(xd, y, dy.to(dev), accumulate=True, need_dx=False)
+        assert rel(lin.dw, 2 * wr.grad) < 1e-5 and rel(lin.db, 2 * br.grad) < 1e-5
+    # weighted cross-entropy
+    lib = capi.load_library()
+    for cw in (None, torch.tensor([1.0, 4.2, 0.5])):
+        logits = torch.randn(300, 3)
+        labels = torch.randint(0, 3, (300,))
+        lr_ = logits.clone().requires_grad_(True)
+        loss_r = torch.nn.functional.cross_entropy(lr_, labels, weight=cw)
+        loss_r.backward()
+        ld, lab = logits.to(dev), labels.to(dev)
+        loss, dl, scratch = torch.empty((), device=dev), torch.empty_like(ld), torch.zeros(2, device=dev)
+        capi._check(lib.hipac_cross_entropy_fwd_bwd(ld.data_ptr(), lab.data_ptr(), None if cw is None else cw.to(dev).data_ptr(),
+                                                    300, 3, loss.data_ptr(), dl.data_ptr(), scratch.data_ptr(), capi._stream()), "ce")
+        assert abs(float(loss) - float(loss_r)) < 1e-5 and rel(dl, lr_.grad) < 1e-5
+    # Adam
+    flat = TN.FlatAdam(5000, dev, 1e-3)
+    p0 = torch.randn(5000)
+    flat.params.copy_(p0)
+    q, m, v = p0.clone(), torch.zeros(5000), torch.zeros(5000)
+    for t in range(1, 4):
+        g = torch.randn(5000)
+        flat.grads.copy_(g)
+        flat.step()
+        q, m, v = TR.adam_ref(q, g, m, v, t, 1e-3)
+        assert torch.allclose(flat.params.cpu(), q, rtol=1e-5, atol=1e-7)
+
+
+def test_simclr_step_every_gradient_against_oracle_autograd():
+    """B = 8 views per side (SURVEY a-12): z_i = model(x_i); z_j = model(x_j); NT-Xent; backward -- per-replica BN."""
+    torch.manual_seed(11)
+    model = SimCLRModel()
+    _randomise_bn(model, 4)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x_i, x_j = torch.randn(8, 3, 224, 224), torch.randn(8, 3, 224, 224)
+    tr = TN.NativeSimCLRTrainer(sd, device="cuda", lr=1e-3)
+    loss = tr.forward_backward(x_i.cuda(), x_j.cuda())
+    torch.cuda.synchronize()
+    m_i, m_j = patterns(tr.encoder, 0, tr.last_hidden[0]), patterns(tr.encoder, 1, tr.last_hidden[1])
+    from oracle.resnet18_ref import canonical_state_dict
+    bare = canonical_state_dict({k: v for k, v in sd.items() if not k.startswith("projector.")})
+    n_dis = count_disagreements(bare, x_i, m_i)
+    print(f"ReLU units switched differently by the oracle's own forward (view i): {n_dis} of ~5.3 M")
+    assert n_dis <= 40
+    loss_ref, grads_ref, stats_ref = TR.simclr_step_ref(sd, x_i, x_j, masks_i=m_i, masks_j=m_j)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)) + 1e-6
+    got = tr.grad_dict()
+    errs = {name: rel(got[name], g) for name, g in grads_ref.items()}
+    print({k: f"{v:.1e}" for k, v in errs.items() if k.endswith("weight") and ("conv" in k or "downsample.0" in k or "projector" in k)})
+    worst = max(errs.items(), key=lambda t: t[1])
+    for name, g in grads_ref.items():
+        assert got[name].shape == g.shape and errs[name] <= GRAD_TOL, (name, errs[name])
+    print(f"simclr step: loss {float(loss):.6f} (oracle {float(loss_ref):.6f}); worst gradient {worst[0]} {worst[1]:.2e}")
+    new = tr.state_dict()
+    for k, v in stats_ref.items():
+        assert rel(new[k], v) <= 1e-4, k
+    assert int(new["encoder.bn1.num_batches_tracked"]) == 2
+    # one optimizer step, then the parameters against Adam applied to the oracle's gradients
+    tr.encoder.opt.step(), tr.head.step()
+    after = tr.state_dict()
+    for name in ("encoder.conv1.weight", "encoder.layer3.0.downsample.0.weight", "encoder.layer4.1.bn2.bias", "projector.2.weight"):
+        p, _, _ = TR.adam_ref(sd[name], grads_ref[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]), 1, 1e-3)
+        # Adam's first step moves every entry by ~lr * sign(g): compare the moves where the gradient is not negligible
+        big = grads_ref[name].abs() > 1e-3 * grads_ref[name].abs().max()
+        assert torch.allclose(after[name][big], p[big], atol=2e-5), name
+
+
+def test_classifier_step_against_oracle_autograd():
+    """The fine-tune step (src/main.py:499-506): CE with class weights, B = 8, every gradient."""
+    torch.manual_seed(13)
+    model = ResNet18Classifier()
+    _randomise_bn(model, 6)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x, y = torch.randn(8, 3, 224, 224), torch.tensor([0, 1, 1, 0, 0, 0, 1, 0])
+    w = torch.tensor([1.0, 2.5])
+    tr = TN.NativeClassifierTrainer(sd, device="cuda", lr=1e-4, class_weights=w)
+    loss, logits = tr.forward_backward(x.cuda(), y.cuda())
+    loss_ref, logits_ref, grads_ref, _ = TR.classifier_step_ref(sd, x, y, w, masks=patterns(tr.encoder, 0))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 and rel(logits, logits_ref) <= 1e-4
+    got = tr.grad_dict()
+    for name, g in grads_ref.items():
+        assert rel(got[name], g) <= GRAD_TOL, (name, rel(got[name], g))
+    out = tr.state_dict()
+    assert set(out) == set(sd)  # the reference's key layout (model.*), ready for torch.save / load_state_dict
+    model.load_state_dict(out)
+
+
+def test_odd_batch_and_workspace_reuse():
+    """Batch sizes that are not multiples of the kernels' tiles; a second step in the same workspaces."""
+    torch.manual_seed(17)
+    model = SimCLRModel()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    tr = TN.NativeSimCLRTrainer(sd, device="cuda")
+    for n in (3, 5):
+        x_i, x_j = torch.randn(n, 3, 224, 224), torch.randn(n, 3, 224, 224)
+        cur = tr.state_dict()
+        loss = tr.forward_backward(x_i.cuda(), x_j.cuda())
+        loss_ref, grads_ref, _ = TR.simclr_step_ref(cur, x_i, x_j, masks_i=patterns(tr.encoder, 0, tr.last_hidden[0]),
+                                                    masks_j=patterns(tr.encoder, 1, tr.last_hidden[1]))
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)) + 1e-6
+        got = tr.grad_dict()
+        for name in ("encoder.conv1.weight", "encoder.layer1.0.conv1.weight", "encoder.layer2.0.downsample.0.weight",
+                     "encoder.layer4.1.conv2.weight", "encoder.bn1.weight", "projector.0.bias"):
+            assert rel(got[name], grads_ref[name]) <= GRAD_TOL, (n, name)

@@ -95,3 +95,32 @@ def test_rgba_samples_and_odd_tile_size(tmp_path):
                         offsets=[0], counts=[raw.size], jpeg_tables=None, subfile_type=0)
     s._buf = memoryview(raw.tobytes())
     np.testing.assert_array_equal(s._decode_tile(fake, 0), rgb[:128, :128])
+
+
+@pytest.mark.parametrize("bigtiff", [False, True])
+def test_abbreviated_jpeg_tables_path(tmp_path, bigtiff):
+    """JPEGTables (tag 347) + abbreviated tile streams -- the form real CAMELYON16 files use: the reader splices
+    the tables back in; pixels equal those of the same tiles written as complete JPEGs and what libtiff decodes."""
+    levels = pyramid(seed=3)
+    full, abbr = str(tmp_path / "full.tif"), str(tmp_path / "abbr.tif")
+    tp.write_tiled_tiff(full, levels, tile=256, compression="jpeg", bigtiff=bigtiff)
+    tp.write_tiled_tiff(abbr, levels, tile=256, compression="jpeg", bigtiff=bigtiff, jpeg_tables=True)
+    a, b = tp.TiffPyramid(full), tp.TiffPyramid(abbr)
+    assert all(lv.jpeg_tables is None for lv in a.levels)
+    assert all(lv.jpeg_tables and lv.jpeg_tables[:2] == b"\xff\xd8" and lv.jpeg_tables[-2:] == b"\xff\xd9" for lv in b.levels)
+    import os
+    assert os.path.getsize(abbr) < os.path.getsize(full)  # the tables are stored once per level, not per tile
+    im = Image.open(abbr)
+    for li in range(3):
+        lv = b.levels[li]
+        got = np.concatenate([b.read_band(li, tr) for tr in range(lv.tiles_down)], 0)
+        ref = np.concatenate([a.read_band(li, tr) for tr in range(lv.tiles_down)], 0)
+        np.testing.assert_array_equal(got, ref)
+        im.seek(li)
+        np.testing.assert_array_equal(got, np.asarray(im.convert("RGB")))
+    # a tile stream alone is not decodable: the tables really are missing from it
+    lv = b.levels[0]
+    raw = bytes(b._buf[lv.offsets[0]:lv.offsets[0] + lv.counts[0]])
+    assert b"\xff\xdb" not in raw[:64]
+    r = b.read_region((100, 60), 0, (300, 200))
+    np.testing.assert_array_equal(r[..., :3], a.read_region((100, 60), 0, (300, 200))[..., :3])
