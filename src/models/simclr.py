@@ -1,2 +1,3 @@
-"""Same import path and names as the reference's src/models/simclr.py."""
-from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel, nt_xent_loss  # noqa: F401
+"""Import-path shim: ``from src.models.simclr import ...`` as in the reference."""
+from ss25_hierarchical_multiscale_image_classification_amd.simclr import (  # noqa: F401
+    SimCLRModel, get_simclr_transform, nt_xent_loss, pretrain_simclr)

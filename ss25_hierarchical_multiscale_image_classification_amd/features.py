@@ -62,6 +62,18 @@ def extract_features_from_pngs(patch_dir: str, net: capi.PackedResNet18, batch_s
     return torch.cat(feats), np.array(labels), paths
 
 
+def extract_features_with_simclr(patch_dir: str, encoder_path: str = "simclr_encoder.pth", precision: str = "bf16",
+                                 batch_size: int = 512, device: str = "cuda"):
+    """src/main.py:897-932: the PNG-tree flow with ``UnifiedResNet(encoder_path, classifier=False)``, i.e. a SimCLR
+    checkpoint's ``encoder.*`` tensors (fc = Identity -> [N,512]); the projector is not used."""
+    from .weights import canonical_state_dict
+
+    sd = canonical_state_dict(torch.load(encoder_path, map_location="cpu", weights_only=True))
+    sd = {k: v for k, v in sd.items() if not k.startswith(("fc.", "projector."))}
+    return extract_features_from_pngs(patch_dir, capi.PackedResNet18(sd, precision=precision), batch_size=batch_size,
+                                      device=device)
+
+
 def save_feature_files(level: int, feats, labels, paths, out_dir: str = "."):
     """src/main.py:885-893."""
     np.save(os.path.join(out_dir, f"patch_features_{level}.npy"), np.asarray(feats, dtype=np.float32))

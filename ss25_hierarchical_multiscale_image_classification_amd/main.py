@@ -56,6 +56,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weights", type=str, default=None, help="state_dict (.pth, any reference key layout)")
     p.add_argument("--stride", type=int, default=None, help="window stride (default: the reference's 224)")
     p.add_argument("--epochs", type=int, default=None)
+    p.add_argument("--simclr_epochs", type=int, default=200, help="pre-training epochs of --strategy self_supervised (:557)")
+    p.add_argument("--simclr_encoder", type=str, default=None,
+                   help="--extract_features with a SimCLR encoder checkpoint (extract_features_with_simclr, src/main.py:897-932)")
     p.add_argument("--batch_size", type=int, default=512)  # BATCH_SIZE, src/main.py:46
     return p
 
@@ -137,6 +140,8 @@ def cmd_extract_features(args):
     from .features import extract_features_from_pngs, extract_features_from_slide, save_feature_files
 
     level = int(args.patch_level) if args.patch_level != "all" else 3  # src/main.py:1134
+    if args.simclr_encoder:  # extract_features_with_simclr: UnifiedResNet(encoder checkpoint, classifier=False)
+        args.weights = args.simclr_encoder
     net = load_net(args, num_classes=None)
     patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
     has_png = os.path.isdir(patch_dir) and any(
@@ -166,7 +171,7 @@ def cmd_train(args, strategy: Optional[str]):
         print("[ERROR] Patches must be extracted before training.")
         return 1
     train_resnet_classifier(patch_dir, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size,
-                            precision=args.precision)
+                            precision=args.precision, simclr_epochs=args.simclr_epochs)
     return 0
 
 

@@ -1,16 +1,18 @@
-"""Host-side mirror of src/models/simclr.py (SimCLRModel, nt_xent_loss).
+"""Host-side mirror of src/models/simclr.py (SimCLRModel, nt_xent_loss, get_simclr_transform,
+pretrain_simclr).
 
-Scope note (SURVEY.md section 8, rows a-12/a-13 are "next"): the SimCLR training step
-is not yet a native HIP path.  ``SimCLRModel`` keeps the reference's parameter tree and
-key layout (``encoder.*``, ``projector.{0,2}.*``) and, in eval mode, runs the encoder on
-the HIP path; in train mode it is an ordinary autograd graph.  ``nt_xent_loss`` is the
-loss exactly as the reference defines it, written with torch ops, with an optional
-``gather`` hook so a process-per-GPU run sees the GLOBAL batch of negatives as
-nn.DataParallel does in the reference (loss computed on the gathered outputs,
-src/models/simclr.py:88-95).
+``SimCLRModel`` keeps the reference's parameter tree and key layout (``encoder.*``,
+``projector.{0,2}.*``); in eval mode its encoder runs on the HIP inference path.  The TRAINING step
+is native too: ``pretrain_simclr`` drives ``train_native.NativeSimCLRTrainer`` (train-mode encoder
+forward / backward, projector, NT-Xent, Adam: csrc/train.hip, csrc/ntxent.hip) and uses this module
+only for the initial weights and the checkpoint format.  ``nt_xent_loss`` is the loss exactly as the
+reference defines it, with an optional ``gather`` hook so a process-per-GPU run sees the GLOBAL batch
+of negatives as nn.DataParallel does in the reference (src/models/simclr.py:88-95); the
+module's own ``forward`` in train mode (an ordinary autograd graph) is kept for scripts that call it.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
@@ -76,3 +78,66 @@ def nt_xent_loss(z_i: torch.Tensor, z_j: torch.Tensor, temperature: float = 0.5,
     positives = torch.cat([torch.diag(sim, n), torch.diag(sim, -n)]).unsqueeze(1)
     denominator = torch.logsumexp(sim, dim=1, keepdim=True)
     return (-positives + denominator).mean()
+
+
+def get_simclr_transform():
+    """src/models/simclr.py:57-66 (host-side PIL pipeline, see transforms.py)."""
+    from .transforms import simclr_transform
+
+    return simclr_transform()
+
+
+def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr: float = 1e-3, device: str = "cuda",
+                    num_workers: int = 8, out_dir: str = ".", max_steps: Optional[int] = None, verbose: bool = True):
+    """src/models/simclr.py:68-124 with the step on the native kernels: PatchDataset(transform=None) ->
+    SimCLRDataset(two augmented views) -> DataLoader(batch_size, shuffle) -> per batch
+    ``z_i = model(x_i); z_j = model(x_j); loss = nt_xent_loss(z_i, z_j); backward; Adam(lr).step()``.
+    Same bookkeeping: best-loss checkpoint ``simclr_encoder_best.pth``, early-stop check every 20 epochs
+    (patience 20), ``simclr_encoder_epoch{N}.pth`` every 50 epochs, final ``simclr_encoder.pth`` -- all
+    SimCLRModel state_dicts (``encoder.*``, ``projector.*``).  ``max_steps`` (additive) bounds the run for tests.
+    Returns (SimCLRModel with the trained weights, list of per-epoch mean losses)."""
+    from torch.utils.data import DataLoader
+
+    from .patch_dataset import PatchDataset
+    from .simclr_dataset import SimCLRDataset
+    from .train_native import NativeSimCLRTrainer
+
+    base = PatchDataset(patch_dir, transform=None)
+    loader = DataLoader(SimCLRDataset(base, transform=get_simclr_transform()), batch_size=batch_size, shuffle=True,
+                        num_workers=num_workers)
+    dev = torch.device(device)
+    model = SimCLRModel()
+    trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=lr)
+    save = lambda name: torch.save(trainer.state_dict(), os.path.join(out_dir, name))
+    best_loss, no_improve, best_epoch, history, steps = float("inf"), 0, -1, [], 0
+    for epoch in range(epochs):
+        total, n_batches = 0.0, 0
+        for x_i, x_j in loader:
+            loss = trainer.step(x_i.to(dev, torch.float32).contiguous(), x_j.to(dev, torch.float32).contiguous())
+            total += float(loss)
+            n_batches += 1
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+        avg = total / max(1, n_batches)
+        history.append(avg)
+        if verbose:
+            print(f"Epoch {epoch+1}, Loss: {avg:.4f}")
+        if avg < best_loss:
+            best_loss, no_improve, best_epoch = avg, 0, epoch + 1
+            save("simclr_encoder_best.pth")
+        else:
+            no_improve += 1
+        if (epoch + 1) % 20 == 0 and no_improve >= 20:
+            if verbose:
+                print(f"[INFO] Early stopping triggered at epoch {epoch+1}. Best epoch: {best_epoch} with loss {best_loss:.4f}")
+            break
+        if (epoch + 1) % 50 == 0:
+            save(f"simclr_encoder_epoch{epoch+1}.pth")
+        if max_steps is not None and steps >= max_steps:
+            break
+    save("simclr_encoder.pth")
+    model.load_state_dict(trainer.state_dict())
+    if verbose:
+        print("[INFO] SimCLR pretraining complete.")
+    return model, history

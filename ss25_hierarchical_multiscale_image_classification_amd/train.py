@@ -1,9 +1,7 @@
-"""Classifier fine-tune loops (mirror of src/main.py:412-606), kept functional so the
-``--train`` / ``--train_strategy`` flags work.
-
-Scope (SURVEY.md section 8, a-13 = "next"): the TRAINING forward/backward runs on the
-module's ordinary autograd graph; only the per-epoch VALIDATION scoring uses the HIP
-inference path.  A native fwd+bwd is a later row of the scope table.
+"""Classifier fine-tune loops (mirror of src/main.py:412-606) behind the ``--train`` /
+``--train_strategy`` flags.  The training step (train-mode ResNet18 forward + backward, weighted
+cross-entropy, Adam) runs on the native kernels (train_native.py, csrc/train.hip); the per-epoch
+validation scoring uses the HIP inference path.  Data loading and augmentation stay on the host.
 """
 from __future__ import annotations
 
@@ -49,12 +47,15 @@ def get_dataloaders(patch_dir: str, test_ratio: float = 0.2, batch_size: int = 5
 
 
 def class_weights(train_ds: PatchDataset, strategy: Optional[str]) -> Optional[torch.Tensor]:
+    """The loss weights of the two loops: plain ``--train`` uses 1/count normalised by the smaller weight
+    (src/main.py:485-490); ``--train_strategy`` computes total/count for every strategy (:549-552) and applies it
+    for ``weighted_loss`` and ``self_supervised`` (:558, :572) -- ``balanced`` trains unweighted (:566)."""
     counts = train_ds.get_class_counts()
     c0, c1 = max(counts.get(0, 0), 1), max(counts.get(1, 0), 1)
-    if strategy is None:  # src/main.py:485-490: 1/count normalised by the smaller weight
+    if strategy is None:
         w = torch.tensor([1.0 / c0, 1.0 / c1])
         return w / w.min()
-    if strategy == "weighted_loss":  # src/main.py:549-552: total/count
+    if strategy in ("weighted_loss", "self_supervised"):
         tot = c0 + c1
         return torch.tensor([tot / c0, tot / c1])
     return None
@@ -62,31 +63,49 @@ def class_weights(train_ds: PatchDataset, strategy: Optional[str]) -> Optional[t
 
 def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epochs: Optional[int] = None,
                             batch_size: int = 512, precision: str = "bf16", lr: float = 1e-4,
-                            save_path: Optional[str] = None, device: str = "cuda"):
+                            save_path: Optional[str] = None, device: str = "cuda", simclr_epochs: int = 200,
+                            simclr_path: str = "simclr_encoder.pth", max_steps: Optional[int] = None):
+    """``train_resnet_classifier`` (strategy None, 30 epochs, src/main.py:472-534) and
+    ``train_resnet_classifier_strategic`` (5 epochs, :536-606).  The training step runs on the native kernels
+    (``train_native.NativeClassifierTrainer``: fp32 -- the reference's fp16 autocast + GradScaler is not imitated);
+    validation scores with the HIP inference path in ``precision``.  ``self_supervised``: pre-trains SimCLR when
+    ``simclr_path`` does not exist (:556-557), then starts the classifier from that encoder -- what the reference
+    means to do (its constructor call raises a TypeError there)."""
+    from .train_native import NativeClassifierTrainer
+    from .weights import canonical_state_dict
+
     epochs = epochs if epochs is not None else (30 if strategy is None else 5)  # :494 / :575
     train_loader, val_loader, train_ds, val_ds = get_dataloaders(patch_dir, 0.2, batch_size,
                                                                  balanced=strategy == "balanced")
     dev = torch.device(device)
-    model = ResNet18Classifier().to(dev).set_precision(precision)
+    model = ResNet18Classifier().set_precision(precision)
+    if strategy == "self_supervised":
+        if not os.path.exists(simclr_path):
+            from .simclr import pretrain_simclr
+
+            pretrain_simclr(patch_dir, epochs=simclr_epochs, batch_size=batch_size, device=device,
+                            out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps)
+        enc = canonical_state_dict(torch.load(simclr_path, map_location="cpu", weights_only=True))
+        sd = model.state_dict()
+        for k, v in enc.items():  # encoder.* -> model.*; the projector is dropped, model.fc keeps its init
+            if not k.startswith("projector.") and ("model." + k) in sd:
+                sd["model." + k] = v
+        model.load_state_dict(sd)
     w = class_weights(train_ds, strategy)
-    criterion = nn.CrossEntropyLoss(weight=w.to(dev) if w is not None else None)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
-    history = []
+    trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w)
+    history, steps = [], 0
     for epoch in range(epochs):
-        model.train()
         total, correct, seen = 0.0, 0, 0
         for imgs, labels, _ in train_loader:
-            imgs, labels = imgs.to(dev), labels.to(dev)
-            opt.zero_grad()
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dev.type == "cuda"):
-                out = model(imgs)
-                loss = criterion(out.float(), labels)
-            loss.backward()
-            opt.step()
+            loss, logits = trainer.step(imgs.to(dev, torch.float32).contiguous(), labels)
             total += float(loss)
-            correct += int((out.argmax(1) == labels).sum())
+            correct += int((logits.argmax(1).cpu() == labels).sum())
             seen += int(labels.numel())
-        model.eval()  # validation scoring on the HIP path
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+        model.load_state_dict(trainer.state_dict())
+        model.to(dev).eval()  # validation scoring on the HIP inference path (BN folded from the running statistics)
         v_correct, v_seen = 0, 0
         with torch.no_grad():
             for imgs, labels, _ in val_loader:
@@ -95,9 +114,15 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
                 v_seen += int(labels.numel())
         history.append((total, correct / max(seen, 1), v_correct / max(v_seen, 1)))
         print(f"Epoch {epoch+1}, Train Loss: {total:.4f}, Train Acc: {history[-1][1]:.4f}, Val Acc: {history[-1][2]:.4f}")
+        if strategy is None and (epoch + 1) % 10 == 0 and save_path is None:  # :528-531
+            os.makedirs(os.path.join("src", "models"), exist_ok=True)
+            torch.save(trainer.state_dict(), os.path.join("src", "models", f"resnet18_patch_classifier_epoch{epoch+1}.pth"))
+        if max_steps is not None and steps >= max_steps:
+            break
     if save_path is None:
         name = "resnet18_patch_classifier.pth" if strategy is None else f"resnet18_patch_classifier_{strategy}.pth"
         save_path = os.path.join("src", "models", name)  # src/main.py:533 / :605
     os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
-    torch.save(model.state_dict(), save_path)
+    torch.save(trainer.state_dict(), save_path)
+    model.load_state_dict(trainer.state_dict())
     return model, history

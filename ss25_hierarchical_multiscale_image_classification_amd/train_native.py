@@ -215,18 +215,23 @@ def _all_reduce_sum(t: torch.Tensor):
     import torch.distributed as dist
 
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)  # SUM: nn.DataParallel reduce-adds the replicas' gradients
+        if t.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)  # SUM: nn.DataParallel reduce-adds the replicas' gradients
 
 
 def _all_gather_rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """(rows of every rank concatenated rank-major, first row of this rank); equal row counts per rank."""
     import torch.distributed as dist
 
+    from .dist import all_gather_equal
+
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return t, 0
-    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
-    return out, dist.get_rank() * t.shape[0]
+    return all_gather_equal(t), dist.get_rank() * t.shape[0]
 
 
 class NativeSimCLRTrainer:
