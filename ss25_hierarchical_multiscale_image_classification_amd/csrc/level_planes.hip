@@ -16,6 +16,8 @@
 // small-integer dot product (s^2 + sum w_t p_t) >> log2(2 s^2), done with v_dot4_u32_u8.
 // The 224x224 "cell" sums needed for the whiteness test (a window = s x s cells) fall out of
 // the same pass over the source.  Pixels are kept as RGBX dwords in the H and D images.
+#include <stdlib.h>
+
 #include <type_traits>
 #include <vector>
 
@@ -102,9 +104,10 @@ __device__ __forceinline__ unsigned edge_pixel(const unsigned (&d)[NDW], const i
     constexpr int t = decltype(TT)::value;
     constexpr int bo = CB0 + 3 * (P0 + t);
     const int kv = kt[t];
-    a0 += cover_byte<bo>(d) * kv;
-    a1 += cover_byte<bo + 1>(d) * kv;
-    a2 += cover_byte<bo + 2>(d) * kv;
+    // 24-bit multiplies (v_mad_i32_i24, full rate; a 32-bit v_mul_lo is quarter rate): byte < 2^8, kv < 2^23
+    a0 += __mul24(cover_byte<bo>(d), kv);
+    a1 += __mul24(cover_byte<bo + 1>(d), kv);
+    a2 += __mul24(cover_byte<bo + 2>(d), kv);
   });
   return clip8p(a0) | (clip8p(a1) << 8) | (clip8p(a2) << 16) | 0xff000000u;
 }
@@ -265,6 +268,209 @@ __global__ __launch_bounds__(256) void vpass_kernel(const unsigned* __restrict__
   dimg[(long long)rr * gm.HW + col] = out;
 }
 
+// ---------------------------------------------------------------------------------------
+// K1+K2 fused ("planes_kernel", the one that runs): horizontal AND vertical pass in one sweep over the source.
+// thread = one group of 8 source pixels x a strip of 112 OWNED source rows (+ S/2 halo rows on either side:
+// 120 of 112 rows read, 1.07x): the horizontal result of every row (NOUT dense pixels, plus the clamped
+// left / right edge pixel for the groups that carry one) never leaves the registers -- each row adds into
+// two running vertical sums per output column (the rising half of output row rr and the falling half of
+// rr - 1: Pillow's triangle weights 2t + 1 and 2S - 1 - 2t), and a D pixel is emitted every S rows.  The
+// clamped top / bottom window rows (general 22-bit weights) accumulate the same way over the 3S/2 rows they
+// cover; strips start at multiples of 112 rows, so those ranges (rows 0..3S/2-1 and 224-3S/2..223 modulo
+// 224) never straddle a strip.  The H image (1.6 GB written and read back per 50 000^2 level) no longer
+// exists: source bytes once (+7 %), D image written once.
+// ---------------------------------------------------------------------------------------
+template <int S, bool EDGE>
+__device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, int W, int H, long long pitch,
+                                             const PlaneGeom& gm, const int* __restrict__ bounds,
+                                             const int* __restrict__ kk, int ksize, unsigned* __restrict__ dimg,
+                                             unsigned* __restrict__ cells, int h, bool live) {
+  constexpr int CB0 = S == 8 ? 12 : (S == 4 ? 8 : 4);
+  constexpr int NDW = S == 8 ? 12 : (S == 4 ? 10 : 8);
+  constexpr int NOUT = 8 / S;
+  constexpr int LOG2 = S == 8 ? 7 : (S == 4 ? 5 : 3);
+  constexpr int OWN = 112;                 // owned rows per strip
+  constexpr int GPC = kLat / 8;
+  constexpr int NC = EDGE ? NOUT + 2 : NOUT;  // output columns of a thread: dense (+ left edge, right edge)
+  constexpr int ECNT = 3 * S / 2;          // taps of the clamped edge kernels
+  const int lane = threadIdx.x & 63;
+  const int y_own = blockIdx.y * OWN;
+  const long long cb = 24LL * h - CB0;
+  const long long wbytes = 3LL * W;
+  const int hm = h % GPC, win_i = h / GPC;
+  const bool is_left = live && hm == 0 && win_i < gm.NX;
+  const int hr = h - (S * kLat / 8 - 1);
+  const bool is_right = live && hr >= 0 && hr % GPC == 0 && hr / GPC < gm.NX;
+  const int right_i = hr / GPC;
+  // D columns of this thread's outputs (-1: none)
+  int dcol[NC];
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) dcol[k] = live ? h * NOUT + k : -1;
+  if constexpr (EDGE) {
+    dcol[NOUT] = is_left ? gm.G + win_i : -1;
+    dcol[NOUT + 1] = is_right ? gm.G + gm.NX + right_i : -1;
+  }
+
+  unsigned a_rb[NC], a_g[NC], p_rb[NC], p_g[NC], b_rb[NC], b_g[NC];  // this block's R and P sums; previous block's R
+  int e0[NC], e1[NC], e2[NC];                                         // clamped top / bottom row kernel
+#pragma unroll
+  for (int c = 0; c < NC; ++c) a_rb[c] = a_g[c] = p_rb[c] = p_g[c] = b_rb[c] = b_g[c] = 0u, e0[c] = e1[c] = e2[c] = 1 << 21;
+  unsigned gsum = 0;
+  const int top0 = bounds[0], bot0 = bounds[2 * 223];  // first source row (relative to the window) of the edge kernels
+  auto load_row = [&](int rr, unsigned (&d)[NDW]) {
+    const int y = y_own - S / 2 + rr;
+    const bool row_ok = y >= 0 && y < H && rr < OWN + S;
+    const uint8_t* rowp = level + (long long)(row_ok ? y : 0) * pitch;
+    if (live && row_ok && cb >= 0 && cb + 4 * NDW <= wbytes) {
+      const uint8_t* q = rowp + cb;
+#pragma unroll
+      for (int k = 0; k + 4 <= NDW; k += 4) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(q + 4 * k);
+        d[k] = v[0], d[k + 1] = v[1], d[k + 2] = v[2], d[k + 3] = v[3];
+      }
+      if constexpr (NDW % 4 == 2) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(q + 4 * (NDW - 2));
+        d[NDW - 2] = v[0], d[NDW - 1] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDW; ++k) {
+        const long long o = cb + 4 * k;
+        unsigned v = 0xffffffffu;
+        if (live && row_ok && o >= 0 && o + 4 <= pitch) {
+          v = *reinterpret_cast<const unsigned*>(rowp + o);
+          const long long nv = wbytes - o;
+          if (nv < 4) v |= nv <= 0 ? 0xffffffffu : (0xffffffffu << (8 * (int)nv));
+        }
+        d[k] = v;
+      }
+    }
+  };
+  auto process_row = [&](int rr, const unsigned (&d)[NDW]) {
+    const int y = y_own - S / 2 + rr;
+    // ---- horizontal pass of this row: the thread's pixels, RGBX ----
+    unsigned px[NC];
+    static_for<NOUT>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      unsigned p = 0xff000000u;
+      static_for<3>([&](auto CH) {
+        constexpr int ch = decltype(CH)::value;
+        unsigned x = 0;
+        static_for<NDW>([&](auto DW) {
+          constexpr int dw = decltype(DW)::value;
+          constexpr unsigned wt = interior_wdword<S>(k, ch, dw);
+          if constexpr (wt != 0) x = __builtin_amdgcn_udot4(d[dw], wt, x, false);
+        });
+        p |= ((S * S + x) >> LOG2) << (8 * ch);
+      });
+      px[k] = p;
+    });
+    if constexpr (EDGE) {
+      // (one merged per-lane chain with the lane's weights in registers was measured: 2.55 vs 2.46 ms at P = 1792
+      // -- the 12 weight registers cost a wave of occupancy -- 2.02 vs 2.18 at 896, 2.86 vs 2.68 at 448)
+      px[NOUT] = px[NOUT + 1] = 0u;
+      if (is_left) px[NOUT] = edge_pixel<S, 0>(d, kk);
+      if (is_right) px[NOUT + 1] = edge_pixel<S, 8 - 3 * S / 2>(d, kk + 223 * ksize);
+    }
+    // whiteness sums over the OWNED rows only (halo rows belong to the neighbouring strips)
+    const bool owned = rr >= S / 2 && rr < S / 2 + OWN && y < gm.HROWS;
+    if (live && owned) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gsum = __builtin_amdgcn_sad_u8(d[CB0 / 4 + k], 0u, gsum);
+    }
+    // ---- vertical pass, interior rows.  Inside a block of S rows (t = rr mod S) the row feeds the rising half
+    // of output rr with weight 2t + 1 and the falling half of output rr - 1 with 2S - 1 - 2t = 2S - (2t + 1):
+    // so only R = sum (2t + 1) p_t (one 24-bit mad) and P = sum p_t are kept, the falling part is 2S P - R.
+    // R and B share a dword as 16-bit lanes (<= 255 * 2 S^2 < 65536; 2S P >= R in every lane: no borrow).
+    const unsigned t = (unsigned)(rr % S), wa = 2 * t + 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const unsigned rb = px[c] & 0x00ff00ffu, g = (px[c] >> 8) & 0xffu;
+      a_rb[c] += __umul24(rb, wa), a_g[c] += __umul24(g, wa);
+      p_rb[c] += rb, p_g[c] += g;
+    }
+    if (t == S - 1) {  // output row rr_out = (y_own + rr + 1) / S - 2 completes (uniform)
+      const int rr_out = (y_own + rr + 1 - 2 * S) / S;
+      const bool emit = rr >= S && rr_out < gm.GY;  // the first block of a strip only starts the next row's rising half
+      const int row0 = S * rr_out - S / 2;
+      const bool unused = row0 < 0 || row0 + 2 * S > gm.HROWS;  // first / last dense row: never gathered
+      unsigned* drow = dimg + (long long)rr_out * gm.HW;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const unsigned tot_rb = b_rb[c] + (2 * S * p_rb[c] - a_rb[c]), tot_g = b_g[c] + (2 * S * p_g[c] - a_g[c]);
+        const unsigned r = ((tot_rb & 0xffffu) + S * S) >> LOG2, b = ((tot_rb >> 16) + S * S) >> LOG2;
+        const unsigned gg = (tot_g + S * S) >> LOG2;
+        if (emit && dcol[c] >= 0) drow[dcol[c]] = unused ? 0xff000000u : (r | (gg << 8) | (b << 16) | 0xff000000u);
+        b_rb[c] = a_rb[c], b_g[c] = a_g[c], a_rb[c] = a_g[c] = p_rb[c] = p_g[c] = 0u;
+      }
+    }
+    // ---- vertical pass, clamped window rows (top: window row 0, bottom: window row 223) ----
+    if (owned) {
+      const int ym = y % kLat;
+      int te = -1, iy = 0, jrow = 0;
+      if (ym >= top0 && ym < top0 + ECNT) te = ym - top0, iy = y / kLat, jrow = 0;
+      else {
+        const int yb = y - bot0;  // = 224 iy + t
+        if (yb >= 0 && yb % kLat < ECNT) te = yb % kLat, iy = yb / kLat, jrow = 223;
+      }
+      if (te >= 0 && iy < gm.NY) {
+        const int kv = kk[jrow * ksize + te];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          e0[c] += __mul24((int)(px[c] & 255u), kv), e1[c] += __mul24((int)((px[c] >> 8) & 255u), kv);
+          e2[c] += __mul24((int)((px[c] >> 16) & 255u), kv);
+        }
+        if (te == ECNT - 1) {
+          unsigned* drow = dimg + (long long)(gm.GY + (jrow ? gm.NY : 0) + iy) * gm.HW;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            if (dcol[c] >= 0) drow[dcol[c]] = clip8p(e0[c]) | (clip8p(e1[c]) << 8) | (clip8p(e2[c]) << 16) | 0xff000000u;
+            e0[c] = e1[c] = e2[c] = 1 << 21;
+          }
+        }
+      }
+    }
+  };
+  // (a 3-deep register ring of prefetched rows was measured slower: 145 VGPRs, one wave per SIMD fewer)
+  for (int rr = 0; rr < OWN + S; ++rr) {
+    unsigned d[NDW];
+    load_row(rr, d);
+    process_row(rr, d);
+  }
+  // cell sums: segmented reduction over the lanes of a wave that share a cell column
+  const int cx = live ? h / GPC : -1 - lane;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(gsum, off, 64);
+    const int cup = __shfl_up(cx, off, 64);
+    if (lane >= off && cup == cx) gsum += up;
+  }
+  const int cnext = __shfl_down(cx, 1, 64);
+  if (live && (lane == 63 || cnext != cx)) atomicAdd(&cells[(y_own / kLat) * gm.NCX + cx], gsum);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void planes_kernel(const uint8_t* __restrict__ level, int W, int H, long long pitch,
+                                                     PlaneGeom gm, const int* __restrict__ bounds,
+                                                     const int* __restrict__ kk, int ksize,
+                                                     unsigned* __restrict__ dimg, unsigned* __restrict__ cells,
+                                                     int n_edge_waves) {
+  constexpr int GPC = kLat / 8;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform by construction
+  if (n_edge_waves < 0) {  // natural order: every wave carries its 4-5 edge groups (measured faster, see the launch)
+    const int h = wave * 64 + lane;
+    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+  } else if (__builtin_amdgcn_readfirstlane(wave) < n_edge_waves) {
+    const int e = wave * 64 + lane;                       // edge group index: (window column, left | right)
+    const int h = (e >> 1) * GPC + ((e & 1) ? GPC - 1 : 0);
+    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+  } else {
+    const int j = (wave - n_edge_waves) * 64 + lane;      // interior group index: 26 of every 28
+    const int h = (j / (GPC - 2)) * GPC + 1 + j % (GPC - 2);
+    planes_strip<S, false>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+  }
+}
+
 // K3: window sums from cell sums; keep = sum <= 240*3*P*P
 __global__ void window_stats_kernel(const unsigned* __restrict__ cells, PlaneGeom gm, const int* __restrict__ xy,
                                     int n, unsigned* __restrict__ sums, unsigned char* __restrict__ keep,
@@ -404,10 +610,30 @@ int hipac_level_build_planes(const uint8_t* level, int W, int H, int64_t pitch, 
   }
   hipStream_t s = (hipStream_t)stream;
   HIPAC_CHECK_HIP(hipMemsetAsync(cells, 0, (size_t)g.NCX * g.NCY * 4, s));
-  dim3 g1((g.NGRP + 255) / 256, (g.HROWS + 15) / 16);
-  dim3 g2((g.HW + 255) / 256, g.DROWS);
   unsigned* hi = (unsigned*)himg;
   unsigned* di = (unsigned*)dimg;
+  const char* env = getenv("HIPAC_PLANES_FUSED");
+  if (!env || atoi(env) != 0) {
+    // fused horizontal + vertical pass (the H image is not touched)
+    // HIPAC_PLANES_SPLIT=1 deals the edge groups (h mod 28 in {0, 27}) to waves of their own; measured slower
+    // (50 000^2: 2.44 vs 2.46 ms at P = 1792, 2.55 vs 2.18 at 896, 3.22 vs 2.68 at 448: the edge waves' loads
+    // do not coalesce and they finish last), so the natural order is the default
+    const char* env_split = getenv("HIPAC_PLANES_SPLIT");
+    const bool split = env_split && atoi(env_split) != 0;
+    const int n_cols28 = (g.NGRP + 27) / 28;                       // blocks of 28 groups
+    const int n_edge_waves = split ? (2 * n_cols28 + 63) / 64 : -1;
+    const int n_int_waves = (26 * n_cols28 + 63) / 64;
+    dim3 gf(split ? (n_edge_waves + n_int_waves + 3) / 4 : (g.NGRP + 255) / 256, (g.HROWS + 111) / 112);
+    switch (g.s) {
+      case 8: hipLaunchKernelGGL((planes_kernel<8>), gf, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds, coeff_kk, ksize, di, cells, n_edge_waves); break;
+      case 4: hipLaunchKernelGGL((planes_kernel<4>), gf, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds, coeff_kk, ksize, di, cells, n_edge_waves); break;
+      default: hipLaunchKernelGGL((planes_kernel<2>), gf, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds, coeff_kk, ksize, di, cells, n_edge_waves);
+    }
+    HIPAC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  dim3 g1((g.NGRP + 255) / 256, (g.HROWS + 15) / 16);
+  dim3 g2((g.HW + 255) / 256, g.DROWS);
   switch (g.s) {
     case 8:
       hipLaunchKernelGGL((hpass_kernel<8>), g1, dim3(256), 0, s, level, W, H, (long long)pitch, g, coeff_bounds,
