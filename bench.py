@@ -239,9 +239,10 @@ def scan_slide_timed(net, slide, args, world, steps, warmup, dev):
     def step():
         f, l, p, meta = extract.score_slide(slide, net, levels=(0, 1, 2, 3), batch_windows=args.batch_windows,
                                             stride=stride_of)
+        n_local = f.shape[0]
         if world > 1:  # configs[3]: the one exchange of the path -- ragged all-gather, rank-major order
             f, l, meta = hdist.gather_results(f, l, meta)
-        return f.shape[0]
+        return n_local
 
     for _ in range(warmup):
         step()
@@ -269,7 +270,7 @@ def wsi_object(net, args, rank, world, dev, sides):
         try:
             slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
             s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, steps=2 if side <= 50000 else 1, warmup=1, dev=dev)
-            rec = {"s_per_slide": s_per, "windows": n_all, "kept": n_kept, "n_gpus": world,
+            rec = {"s_per_slide": s_per, "windows": n_all, "kept": n_kept, "n_gpus": world, "slides": world,
                    "kept_patches_per_s": world * n_kept / s_per if world == 1 else None,
                    "unique_source_GBps": world * sum(w * h * 3 for (w, h) in slide.level_dimensions) / s_per / 1e9}
             if rank == 0:

@@ -3,7 +3,12 @@
 Cross-compiles without a GPU.  The .so stays inside the package directory so it
 travels with the tree (it is git-ignored, not gpurun-ignored).
 
-    python -m ss25_hierarchical_multiscale_image_classification_amd.build [--force]
+    python -m ss25_hierarchical_multiscale_image_classification_amd.build [--force] [--asan]
+
+``--asan`` builds ``libhipac_hip_asan.so``: the HOST side of every translation unit (argument checks, workspace
+plans, weight packing, Pillow coefficient tables, launch bookkeeping) under AddressSanitizer
+(``-fsanitize=address -fno-gpu-sanitize``; device code is compiled as usual -- GPU ASan is not available on
+this pool).  tests/test_host_asan.py drives its host-only entry points under the ASan runtime.
 """
 from __future__ import annotations
 
@@ -76,5 +81,26 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+def asan_runtime() -> Path:
+    """The clang ASan runtime a non-instrumented python must preload to dlopen the --asan build."""
+    cands = sorted(Path("/opt/rocm/lib/llvm/lib/clang").glob("*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not cands:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return cands[-1]
+
+
+def build_asan(verbose: bool = False) -> Path:
+    """Host-ASan variant, in its own object directory and library name (a child process: the flags are module state)."""
+    env = dict(os.environ, HIPAC_LIB_NAME="libhipac_hip_asan.so", HIPAC_OBJ_DIR="build_asan",
+               HIPAC_EXTRA_FLAGS="-fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -g")
+    r = subprocess.run([sys.executable, str(Path(__file__)), *([] if verbose else ["--quiet"])], env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"asan build failed:\n{r.stdout}\n{r.stderr}")
+    return PKG / "libhipac_hip_asan.so"
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose="--quiet" not in sys.argv))
