@@ -95,8 +95,8 @@ struct Net {
   int precision;
   int num_classes;
   ConvW stem;
-  ConvW stem_u8;      // strip kernel (uint8 input): T[64][192] in its own K order, normalisation folded in
-  float stem_pad[3];  // value of a pixel outside the image, per channel, in the strip kernel's input units
+  ConvW stem_u8;      // strip kernel (uint8 input): T[64][192] in its own K order, normalisation folded in;
+                      // its "bias" is the table float[4 row classes][4 column classes][64]: bias + border correction
   ConvW block[8][2];
   ConvW down[3];
   float* fc_w;  // device float[num_classes][512]

@@ -1243,20 +1243,19 @@ constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 template <typename T>
 __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned char* __restrict__ x,
                                                                   const T* __restrict__ wgt,
-                                                                  const float* __restrict__ bias, T* __restrict__ out,
-                                                                  int n_strips, int in_bytes, float pv0, float pv1,
-                                                                  float pv2) {
+                                                                  const float* __restrict__ btab, T* __restrict__ out,
+                                                                  int n_strips, int in_bytes) {
   using E = Elem<T>;
   using frag = typename E::frag;
   constexpr int NRP = 11, PXW = 128;
   constexpr int PLANE = NRP * PXW * 4;
   constexpr int PATCH_BYTES = 3 * PLANE;              // 16 896
-  constexpr int RAW_PITCH = 528, RAW_ROWS = 22;
+  constexpr int RAW_PITCH = 512, RAW_ROWS = 22;        // one 16-byte DMA instruction brings two rows (lanes 0-24, 32-56)
   constexpr int RAW_BYTES = RAW_ROWS * RAW_PITCH;     // 11 616
   constexpr int TEAM_BYTES = PATCH_BYTES + RAW_BYTES;
   constexpr int CARRY_BYTES = 512 * 64;               // per lane 16 floats: the raw last stem row of the previous step
   constexpr int STG_BYTES = 4 * 14 * 64;              // per wave: 4 pooled rows x 14 pixels x 32 channels of T
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 256];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 4096];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1270,9 +1269,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
   // hold a pooled pixel (8 bytes each), read back as 224 linear 16-byte chunks and stored 64 contiguous
   // bytes per pixel -- per-lane 8-byte stores to 28 different lines cost 2 700 cycles per step
   unsigned char* const Sl = smem + 2 * TEAM_BYTES + CARRY_BYTES + wave * STG_BYTES;
-  // bias in LDS: a global load inside the step loop would wait (vmcnt retires in order) for the rows just requested
+  // Initial accumulators, in LDS (a global load inside the step loop would wait -- vmcnt retires in order -- for the
+  // rows just requested): table [row class][column class][64 channels] = folded bias + the border correction.
+  // The kernel feeds 0 for every byte outside the image (rows and whole dwords of columns are zero-filled by the
+  // DMA's range check: nothing to mask in the conversion), while the reference pads with the normalised 0, i.e. the
+  // byte value mu_c = 255 mean_c: the difference, sum over the taps outside of w mu_c, depends only on which taps
+  // are outside -- stem row 0 / 1 / 111 / other x stem column 0 / 1 / 111 / other -- and is part of the table.
   float* const Bl = reinterpret_cast<float*>(smem + 2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES);
-  if (tid < 64) Bl[tid] = bias[tid];  // visible after the first phase barrier (first read: H1(0))
+  for (int i = tid; i < 16 * 64; i += 512) Bl[i] = btab[i];  // visible after the first phase barrier (first read: H1(0))
   int s_off[4];  // element offset of chunk lane + 64 m from the step's first pixel
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -1293,19 +1297,21 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 
   // rows owned by this wave: window rows 6 tw .. 6 tw + 5 (row pairs 3 tw .. 3 tw + 2); wave 3 owns rows
   // 18 .. 20 (row 21 does not exist)
-  const int own_rows = tw < 3 ? 6 : 3;
+  // (wave 3: rows 18 .. 20; its fourth request covers row 20 and the nonexistent row 21 -> zeros)
   auto issue_dma = [&](int strip, int ys) {
     const int b = strip >> 1, side = strip & 1;
-    const int base = b * (kPatch * kPatch * 3) + (16 * ys - 3) * (kPatch * 3) + 3 * (112 * side - 5) - 1;
-    static_for<6>([&](auto K) {
+    const int base = b * (kPatch * kPatch * 3) + (16 * ys - 3) * (kPatch * 3) + 3 * (112 * side - 5) - 1;  // multiple of 16
+    // lane -> (row of the pair, 16-byte chunk); chunks outside the image columns read as zeros: side 0: chunk 0
+    // (bytes 0..15 = columns -5..-1), side 1: chunks 22.. (columns 224..)
+    const int sub = lane >> 5, ch16 = lane & 31;
+    const bool col_ok = ch16 < 25 && (side == 0 ? ch16 >= 1 : ch16 < 22);
+    static_for<3>([&](auto K) {
       constexpr int k = decltype(K)::value;
-      if (k < own_rows) {
-        const int row = 6 * tw + k;
+      if (tw < 3 || k < 2) {
+        const int row = 6 * tw + 2 * k + sub;
         const int iy = 16 * ys - 3 + row;
-        const bool ok = (unsigned)iy < (unsigned)kPatch;
-        const int off = base + row * (kPatch * 3) + lane * 4;
-        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH, ok ? off : (int)0x80000000, 0);
-        buffer_load_lds4(in_rsrc, Rl + row * RAW_PITCH + 256, ok ? off + 256 : (int)0x80000000, 0);
+        const bool ok = col_ok && (unsigned)iy < (unsigned)kPatch && row < 21;
+        buffer_load_lds16(in_rsrc, Rl + (6 * tw + 2 * k) * RAW_PITCH, ok ? base + row * (kPatch * 3) + ch16 * 16 : (int)0x80000000, 0);
       }
     });
   };
@@ -1315,10 +1321,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
   const bool ctask = (lane >> 4) < (tw < 3 ? 3 : 2);
   const unsigned char* const craw = Rl + (2 * cRp) * RAW_PITCH + cxg * 24;
   unsigned char* const cdst = Pl + cRp * (PXW * 4) + cxg * 32;
-  const unsigned pvpk[3] = {PackPair<T>::pack(pv0, pv0), PackPair<T>::pack(pv1, pv1), PackPair<T>::pack(pv2, pv2)};
   auto convert = [&](int strip, int ys) {
+    (void)strip, (void)ys;
     if (!ctask) return;
-    const int side = strip & 1;
     unsigned da[7], db[7];
     {
       const u32x2 a0 = *reinterpret_cast<const u32x2*>(craw), a1 = *reinterpret_cast<const u32x2*>(craw + 8),
@@ -1331,24 +1336,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
       da[6] = *reinterpret_cast<const unsigned*>(craw + 24);
       db[6] = *reinterpret_cast<const unsigned*>(craw + RAW_PITCH + 24);
     }
-    // rows outside the image (only at the first and the last step of a strip) and the nonexistent window
-    // row 21: replace the half-dword of that row by the pad value
-    const int iya = 16 * ys - 3 + 2 * cRp;
-    const bool oka = (unsigned)iya < (unsigned)kPatch;
-    const bool okb = (unsigned)(iya + 1) < (unsigned)kPatch && cRp < 10;
-    const unsigned keep = (oka ? 0x0000ffffu : 0u) | (okb ? 0xffff0000u : 0u);
-    const int xin0 = 112 * side - 5 + 8 * cxg;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       unsigned o[8];
 #pragma unroll
       for (int px = 0; px < 8; ++px) {
         const int w = 1 + 3 * px + c;  // byte inside the dword run
-        const float fa = (float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu);
-        const float fb = (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu);
-        const unsigned v = PackPair<T>::pack(fa, fb);
-        const bool okx = (unsigned)(xin0 + px) < (unsigned)kPatch;
-        o[px] = okx ? ((v & keep) | (pvpk[c] & ~keep)) : pvpk[c];
+        o[px] = PackPair<T>::pack((float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu), (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu));
       }
       *reinterpret_cast<u32x4*>(cdst + c * PLANE) = u32x4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<u32x4*>(cdst + c * PLANE + 16) = u32x4{o[4], o[5], o[6], o[7]};
@@ -1380,6 +1374,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 #endif
         const int strip = tg + ((n < 0 ? 0 : n) / kStripSteps) * tstride;
         const int ys = (n < 0 ? 0 : n) % kStripSteps;
+#ifdef HIPAC_ABL_STRIP_NO_EPI
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i]));
+        if (n_strips < 0)
+#endif
         if (n >= 0) {
           const int b = strip >> 1, side = strip & 1;
           f32x16 carry;
@@ -1453,52 +1452,88 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             issue_dma(tg, 0);  // prologue: nothing was requested yet
             wait_vmcnt<0>();
           } else {
-            wait_vmcnt<4>();  // this wave's raw rows of step n+1 (requested in H1(n)) are older than its 4 stores
+            wait_vmcnt<4>();  // this wave's raw rows of step n+1 (requested at the end of H2(n-1)) are older than its 4 stores
           }
           HALO_STAMP(z_tw);
+#ifdef HIPAC_ABL_STRIP_NO_CONVERT
+          if (n_strips < 0)
+#endif
           convert(tg + (gn / kStripSteps) * tstride, gn % kStripSteps);
 #ifdef HIPAC_HALO_STAMPS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           HALO_STAMP(z_tc);
           if (n >= 0) z_sum[2] += z_tw - z_te, z_sum[3] += z_tc - z_tw;
 #endif
+          // the raw rows are consumed (this wave converts only rows it requested itself): request those of step n + 2
+          // now, a whole MFMA half ahead of their use -- issuing them at the start of H1 sat in front of the MFMAs
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef HIPAC_ABL_STRIP_NO_DMA
+          if (n_strips < 0)
+#endif
+          if (gn + 1 < n_steps) issue_dma(tg + ((gn + 1) / kStripSteps) * tstride, (gn + 1) % kStripSteps);
         }
       } else {
         // ---------------- H1(n): request the rows of step n + 1, MFMA loop of step n ----------------
-#ifdef HIPAC_ABL_STRIP_NO_DMA
-        if (n_strips < 0)
-#endif
-        if (n + 1 < n_steps) {
-          const int gn = n + 1;
-          issue_dma(tg + (gn / kStripSteps) * tstride, gn % kStripSteps);
-        }
+        f32x16 binit;
         {
-          float4 bv[4];
+          const int strip1 = tg + (n / kStripSteps) * tstride, ys1 = n % kStripSteps, side1 = strip1 & 1;
+          // column class of this lane's stem column (0 interior, 1: column 0, 2: column 1, 3: column 111)
+          const int cc = (side1 == 0 && st == 0) ? (r == 1 ? 1 : (r == 2 ? 2 : 0)) : ((side1 == 1 && st == 1 && r == 28) ? 3 : 0);
+          const float* bl = Bl + cc * 64 + jt * 32 + 4 * h;
+          // rows 2..6 never have a special class: their accumulators start as the C operand of their first MFMA
+          // (binit, 16 registers) instead of 80 v_mov; rows 0, 1, 7 are set here (from the row-class table when needed)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(Bl + jt * 32 + 8 * q + 4 * h);
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(bl + 8 * q);
+            binit[4 * q + 0] = v.x, binit[4 * q + 1] = v.y, binit[4 * q + 2] = v.z, binit[4 * q + 3] = v.w;
+          }
+          acc[0] = binit, acc[1] = binit, acc[7] = binit;
+          if (ys1 == 0 || ys1 == kStripSteps - 1) {  // uniform: stem rows 0, 1 (first step) / 111 (last step) have taps above / below the image
+            static_for<3>([&](auto RC) {
+              constexpr int rc = decltype(RC)::value + 1;
+              constexpr int i = rc == 1 ? 0 : (rc == 2 ? 1 : 7);
+              if ((rc == 3) == (ys1 != 0)) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc[i][4 * q + 0] = bv[q].x;
-              acc[i][4 * q + 1] = bv[q].y;
-              acc[i][4 * q + 2] = bv[q].z;
-              acc[i][4 * q + 3] = bv[q].w;
-            }
+                for (int q = 0; q < 4; ++q) {
+                  const float4 v = *reinterpret_cast<const float4*>(bl + rc * 256 + 8 * q);
+                  acc[i][4 * q + 0] = v.x, acc[i][4 * q + 1] = v.y, acc[i][4 * q + 2] = v.z, acc[i][4 * q + 3] = v.w;
+                }
+              }
+            });
+          }
         }
 #if HIPAC_STRIP_PRIO == 1
         __builtin_amdgcn_s_setprio(1);
 #endif
-#pragma unroll
-        for (int s = 0; s < 12; ++s) {
-          const int c = s >> 2, rp = s & 3;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const unsigned char* pp = fbase + (c * NRP + i + rp) * (PXW * 4);
+        // Fragment (plane c, row pair j) feeds the up to four MFMAs (i, rp) with i + rp = j, so the loop runs over
+        // the 33 fragments, each read ONCE, two fragments ahead of its MFMAs (3-slot register ring, order pinned:
+        // left to itself hipcc issues a read right in front of the MFMA that needs it and exposes the LDS latency
+        // ~25 times per step).  acc[i] is touched at most once per group of 4 MFMAs: no dependent-MFMA stalls.
+#ifdef HIPAC_ABL_STRIP_NO_MFMA
+        if (n_strips < 0)
+#endif
+        {
+          frag ring3[3];
+          auto rd = [&](auto F) {
+            constexpr int f = decltype(F)::value;      // f = c * 11 + j
+            const unsigned char* pp = fbase + f * (PXW * 4);
             const u32x2 lo = *reinterpret_cast<const u32x2*>(pp), hi = *reinterpret_cast<const u32x2*>(pp + 8);
-            const frag af = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
-            acc[i] = E::mfma(wreg[s], af, acc[i]);
-          }
+            ring3[f % 3] = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
+          };
+          rd(std::integral_constant<int, 0>{});
+          rd(std::integral_constant<int, 1>{});
+          static_for<33>([&](auto F) {
+            constexpr int f = decltype(F)::value, c = f / NRP, j = f % NRP;
+            if constexpr (f + 2 < 33) rd(std::integral_constant<int, f + 2>{});
+            static_for<4>([&](auto RP) {
+              constexpr int rp = decltype(RP)::value, i = j - rp;
+              if constexpr (i >= 0 && i < 8) {
+                if constexpr (c == 0 && rp == 0 && i >= 2 && i <= 6) acc[i] = E::mfma(wreg[0], ring3[f % 3], binit);
+                else acc[i] = E::mfma(wreg[c * 4 + rp], ring3[f % 3], acc[i]);
+              }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
 #if HIPAC_STRIP_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -2222,7 +2257,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
         const int sgrid = n_pairs < 256 ? n_pairs : 256;  // persistent: one 8-wave workgroup (two teams) per CU
         hipLaunchKernelGGL((stem_pool_strip2_kernel<T>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
                            (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
-                           ne * kPatch * kPatch * 3, net.stem_pad[0], net.stem_pad[1], net.stem_pad[2]);
+                           ne * kPatch * kPatch * 3);
       } else if (p.u8_input)
         hipLaunchKernelGGL((stem_pool_kernel<T, true>), dim3(grid), dim3(256), 0, s, xin, (const T*)net.stem.w,
                            net.stem.bias, (T*)(ws + p.pool), n_tiles, net.lut_t,

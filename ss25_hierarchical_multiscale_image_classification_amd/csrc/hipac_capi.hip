@@ -253,10 +253,11 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
 
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
 // pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the byte
-// value v itself (exact in bf16 and fp16), so w'' = w * scale / (255 std_c) and the bias takes
-// - sum w'' mu''_c with mu''_c = 255 mean_c over ALL 49 taps (a pixel outside the image carries mu''_c =
-// the normalised 0 the reference pads with).  The fold uses the ROUNDED weights, so what is left of the
-// weight rounding multiplies the centred value x'' - mu'', as in the unfolded form.
+// value v itself (exact in bf16 and fp16) and 0 outside the image, so w'' = w * scale / (255 std_c) and the
+// bias takes - sum w'' mu''_c, mu''_c = 255 mean_c (the byte value of the normalised 0 the reference pads with),
+// over the taps INSIDE the image: one bias per (row class, column class) of the stem pixel, 16 x 64 floats.
+// The fold uses the ROUNDED weights, so what is left of the weight rounding multiplies the centred value
+// v - mu'', as in the unfolded form.
 // K order: k = 16 s + 8 h + j, s = 4 c + rp, kh = 2 rp + (j & 1), kw = 4 h + (j >> 1); kh, kw = 7 are zero.
 static float round_to(float v, int precision) {
   const uint16_t b = to_bits(v, precision);
@@ -270,42 +271,40 @@ static float round_to(float v, int precision) {
   memcpy(&hh, &b, 2);
   return (float)hh;
 }
-static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW* out, float pad[3]) {
+static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW* out) {
   const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
   std::vector<uint16_t> w((size_t)64 * 192, 0);
-  std::vector<float> bias(64);
+  std::vector<float> tab((size_t)16 * 64);
   double mu[3];
-  for (int ch = 0; ch < 3; ++ch) {
-    mu[ch] = 255.0 * mean[ch];
-    pad[ch] = round_to((float)mu[ch], precision);
-  }
+  for (int ch = 0; ch < 3; ++ch) mu[ch] = 255.0 * mean[ch];
+  // taps of a stem pixel that fall outside the image, by class: 0 none, 1: row / column 0 (taps 0-2), 2: row / column 1
+  // (tap 0), 3: row / column 111 (taps 5, 6)
+  auto tap_out = [](int cls, int k) { return cls == 1 ? k <= 2 : (cls == 2 ? k == 0 : (cls == 3 ? k >= 5 : false)); };
   for (int o = 0; o < 64; ++o) {
     const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
-    double b = (double)c.bn_beta[o] - (double)c.bn_mean[o] * scale;
+    double rw[3][7][7];  // rounded weights, as the kernel multiplies them
     for (int ch = 0; ch < 3; ++ch)
       for (int kh = 0; kh < 7; ++kh)
         for (int kw = 0; kw < 7; ++kw) {
           const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale / (255.0 * stdv[ch]);
           const int s = 4 * ch + (kh >> 1), hq = kw >> 2, j = 2 * (kw & 3) + (kh & 1);
-          const uint16_t bits = to_bits((float)v, precision);
-          w[(size_t)o * 192 + 16 * s + 8 * hq + j] = bits;
-          uint16_t tmp = bits;
-          float rounded;
-          if (precision == HIPAC_PREC_BF16) {
-            const uint32_t u = (uint32_t)tmp << 16;
-            memcpy(&rounded, &u, 4);
-          } else {
-            _Float16 hh;
-            memcpy(&hh, &tmp, 2);
-            rounded = (float)hh;
-          }
-          b -= (double)rounded * mu[ch];
+          w[(size_t)o * 192 + 16 * s + 8 * hq + j] = to_bits((float)v, precision);
+          rw[ch][kh][kw] = (double)round_to((float)v, precision);
         }
-    bias[o] = (float)b;
+    const double b0 = (double)c.bn_beta[o] - (double)c.bn_mean[o] * scale;
+    for (int rc = 0; rc < 4; ++rc)
+      for (int cc = 0; cc < 4; ++cc) {
+        double b = b0;  // bias - sum over the taps INSIDE the image of w mu (the kernel feeds 0 outside)
+        for (int ch = 0; ch < 3; ++ch)
+          for (int kh = 0; kh < 7; ++kh)
+            for (int kw = 0; kw < 7; ++kw)
+              if (!tap_out(rc, kh) && !tap_out(cc, kw)) b -= rw[ch][kh][kw] * mu[ch];
+        tab[((size_t)rc * 4 + cc) * 64 + o] = (float)b;
+      }
   }
   int rc = upload(w.data(), w.size() * 2, &out->w);
   if (rc) return rc;
-  return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
+  return upload(tab.data(), tab.size() * 4, (void**)&out->bias);
 }
 
 static void free_convw(ConvW& c) {
@@ -387,7 +386,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   w->net.num_classes = params->num_classes;
   const float eps = params->bn_eps;
   int rc = pack_conv(params->stem, 64, 3, 7, eps, precision, true, &w->net.stem);
-  if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8, w->net.stem_pad);
+  if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
