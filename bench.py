@@ -65,7 +65,7 @@ for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
 assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 
-KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip_kernel", "l1": "conv3x3_c64_kernel", "l2b0c1+proj": "conv3x3s2_c64_kernel",
+KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "conv3x3_c64_kernel", "l2b0c1+proj": "conv3x3s2_c64_kernel",
                 "l3b0c1+proj": "conv_glds_kernel", "l4b0c1": "conv_glds_kernel", "l4proj": "conv_glds_kernel"}
 
 

@@ -115,6 +115,7 @@ struct Plan {
   int u8_input;   // 1: the stem reads raw uint8 HWC patches (normalise fused); needs fuse_stem
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   int stem_strip; // uint8 input: 1 = strip kernel (default), 0 = tile kernel with the LDS table (first form)
+  int l1_fused;   // 1 = a layer1 BasicBlock is one kernel (default), 0 = conv1 and conv2 as separate launches
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]
   size_t stem;    // T[bc,112,112,64]

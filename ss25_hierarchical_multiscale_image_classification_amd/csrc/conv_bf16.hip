@@ -16,4 +16,12 @@ extern "C" int hipac_debug_halo_stamps(unsigned long long* out8, int reset) {
   }
   return 0;
 }
+extern "C" int hipac_debug_blk_stamps(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(hipac::g_blk_stamps), 32) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[4] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hipac::g_blk_stamps), z, 32) != hipSuccess) return 1;
+  }
+  return 0;
+}
 #endif

@@ -1198,6 +1198,9 @@ __device__ __forceinline__ void buffer_load_lds4(rsrc_t rs, void* lds, int voffs
 __device__ inline void buffer_load_lds4(rsrc_t, void*, int, int) {}
 #endif
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 template <typename T> struct PackPair;  // two exactly representable floats -> one dword of two T (lo, hi)
 template <> struct PackPair<_Float16> {
@@ -1205,10 +1208,8 @@ template <> struct PackPair<_Float16> {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));  // exact inputs: the rounding mode is moot
   }
   static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    f16x4 t;  // round-to-nearest-even, as every other store of T in this library
-    t[0] = (_Float16)lo;
-    t[1] = (_Float16)hi;
-    return __builtin_bit_cast(u32x2, t)[0];
+    // round-to-nearest-even, as every other store of T in this library; one packed conversion
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
   }
 };
 template <> struct PackPair<__bf16> {
@@ -1216,10 +1217,7 @@ template <> struct PackPair<__bf16> {
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
   }
   static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    bf16x4 t;
-    t[0] = (__bf16)lo;
-    t[1] = (__bf16)hi;
-    return __builtin_bit_cast(u32x2, t)[0];
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
   }
 };
 
@@ -1692,16 +1690,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
 #ifdef HIPAC_HALO_STAMPS
   unsigned long long c_sum[5] = {0, 0, 0, 0, 0};
 #endif
+  bool stored = false;  // wave-uniform: the previous unit's epilogue issued its 4 stores
   for (int it = 0; u < n_units; u += gridDim.x, ++it) {
     const int buf = it & 1;
     HALO_STAMP(c_t0);
-    wait_vmcnt<0>();
+    // this unit's halo DMAs are OLDER than the 4 stores of the previous epilogue and vmcnt retires in
+    // issue order: leave the stores in flight instead of paying their acknowledgement latency here
+    if (stored) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
     HALO_STAMP(c_t0b);
     __builtin_amdgcn_s_barrier();  // halos of this unit landed; every wave is past its reads of the other buffer
     HALO_STAMP(c_t1);
 
     // this wave's tile and the element offset of its epilogue items (pixel e_px + 16k of sub-tile i)
     const bool tile_ok = 2 * u + wt < n_tiles;
+    stored = tile_ok;
     const int tile = tile_ok ? 2 * u + wt : n_tiles - 1;  // addresses stay inside the tensors; stores are guarded
     const int tb = tile / TPI, tt = tile - tb * TPI;
     const int ty = tt / 7, tx = tt - ty * 7;
@@ -1726,11 +1729,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
     // cost 18 VGPRs next to 144 of weights): make their inputs opaque per iteration
     asm volatile("" : "+v"(lx), "+v"(ly0));
     const unsigned char* const Hl = smem + buf * U_BYTES + wt * H_BYTES;
+    // the bias is the initial accumulator (register group q = channels wn*32 + 8q + 4h .. +3), as in block_c64.h
     f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(Bl + wn * 32 + 8 * q + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = bq[e];
+    }
     __builtin_amdgcn_s_setprio(1);
     // 36 k16 steps (tap-major); the two activation fragments of step s + PF are requested before the
     // MFMAs of step s, so an LDS read has PF MFMA pairs (PF x 64 cycles) to return
@@ -1794,10 +1802,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
         const int ki = SPX == 32 ? k : kk;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROW + e_c8 * 32 + 16);
-        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(Bl + wn * 32 + e_c8 * 8);
-        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(Bl + wn * 32 + e_c8 * 8 + 4);
-        float v[8] = {lo[0] + b_lo[0], lo[1] + b_lo[1], lo[2] + b_lo[2], lo[3] + b_lo[3],
-                      hi[0] + b_hi[0], hi[1] + b_hi[1], hi[2] + b_hi[2], hi[3] + b_hi[3]};
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if constexpr (RESID) {
           const frag rvv = *reinterpret_cast<const frag*>(Rl + (2 * i + ki) * 1024 + lane * 16);
 #pragma unroll
@@ -1938,7 +1943,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_kernel(const T* __restri
   if (tile < n_tiles) issue_unit(tile, 0);
   for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
     const int buf = it & 1;
-    wait_vmcnt<0>();
+    // the halo DMAs are older than the previous epilogue's 4 stores (vmcnt retires in issue order)
+    if (it) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // this tile's halo landed; every wave is past its reads of the other buffer
     if (tile + (int)gridDim.x < n_tiles) issue_unit(tile + gridDim.x, buf ^ 1);  // lands behind this whole unit
 
@@ -2013,6 +2020,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_kernel(const T* __restri
     flush(accp, Bl + CO, false, out_p);
   }
 }
+
+}  // namespace hipac
+#include "block_c64.h"
+namespace hipac {
 
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
 // post-ReLU (>= 0) so the implicit -inf padding never wins; out-of-range taps
@@ -2210,11 +2221,31 @@ struct OpRange {
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
 template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST>
 static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
-                     hipStream_t s, OpRange& ops) {
+                     hipStream_t s, OpRange& ops, bool fuse_blocks = false) {
   constexpr int HO = HI / STRIDE;
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
+  if constexpr (CI == 64 && CO == 64 && HI == 56 && STRIDE == 1 && sizeof(T) == 2) {
+    if (fuse_blocks) {
+      // layer1: each BasicBlock is one launch (conv1 -> conv2 + shortcut on chip); the conv2 op slots stay empty
+      const int per_xcd = 4 * ((n + 7) / 8);                   // strips on the busiest XCD
+      const int grid = 8 * (per_xcd < 32 ? per_xcd : 32);      // persistent: one 8-wave workgroup per CU
+      if (ops.take()) {
+        hipLaunchKernelGGL((block_c64_kernel<T>), dim3(grid), dim3(512), 0, s, (const T*)x, (const T*)bw[0].w,
+                           bw[0].bias, (const T*)bw[1].w, bw[1].bias, (T*)o0, n);
+        HIPAC_TRY((int)hipGetLastError());
+      }
+      (void)ops.take();
+      if (ops.take()) {
+        hipLaunchKernelGGL((block_c64_kernel<T>), dim3(grid), dim3(512), 0, s, (const T*)o0, (const T*)bw1[0].w,
+                           bw1[0].bias, (const T*)bw1[1].w, bw1[1].bias, (T*)o1, n);
+        HIPAC_TRY((int)hipGetLastError());
+      }
+      (void)ops.take();
+      return 0;
+    }
+  }
   // block 0
   const void* idt = x;
   if constexpr (STRIDE == 2 && sizeof(T) == 2 && HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
@@ -2283,7 +2314,8 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
   char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * sizeof(T);
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops)));
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
+                                                p.l1_fused != 0)));
   HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
   HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
   HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops)));

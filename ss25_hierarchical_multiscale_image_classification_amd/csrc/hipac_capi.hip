@@ -60,6 +60,7 @@ Plan make_plan(int batch, int precision) {
   p.fuse_stem = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
+  p.l1_fused = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;

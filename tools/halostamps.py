@@ -28,7 +28,7 @@ for i, name in enumerate(names):
     torch.cuda.synchronize()
     fn(buf, 1)
     n = max(1, buf[3])
-    tot = buf[0] + buf[1] + buf[2]
+    tot = max(1, buf[0] + buf[1] + buf[2])
     print(f"{name}: workgroups {buf[3]}  per workgroup (s_memtime ticks of 10 ns): prologue {buf[0]/n:.0f}  "
           f"K loop {buf[1]/n:.0f}  epilogue {buf[2]/n:.0f}   shares {buf[0]/tot:.2f} / {buf[1]/tot:.2f} / {buf[2]/tot:.2f}")
 
@@ -40,6 +40,6 @@ for i, name in enumerate(names):
     torch.cuda.synchronize()
     fn(buf, 1)
     n = max(1, buf[3])
-    tot = buf[4] + buf[5] + buf[6] + buf[7]
+    tot = max(1, buf[4] + buf[5] + buf[6] + buf[7])
     print(f"{name}: wave-units {buf[3]}  cycles per unit and wave: vmcnt drain {buf[4]/n:.0f}  barrier {buf[5]/n:.0f}  "
           f"DMA issue + MFMA loop {buf[6]/n:.0f}  epilogue {buf[7]/n:.0f}   total {tot/n:.0f}")
