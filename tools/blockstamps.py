@@ -19,7 +19,7 @@ h8, b4 = (ctypes.c_ulonglong * 8)(), (ctypes.c_ulonglong * 4)()
 u8 = synth.synth_patches_u8(512, seed=1, device=dev)
 net.forward(u8)
 torch.cuda.synchronize()
-i = [n for n, _ in bench.OPS].index("l1b0c1")
+i = [n for n, _ in bench.OPS].index("l1b0")
 fh(h8, 1), fb(b4, 1)
 net.run_ops(u8, i, i)
 torch.cuda.synchronize()

@@ -29,7 +29,7 @@ for i, name in enumerate(names):
     fn(buf, 1)
     n = max(1, buf[3])
     tot = max(1, buf[0] + buf[1] + buf[2])
-    print(f"{name}: workgroups {buf[3]}  per workgroup (s_memtime ticks of 10 ns): prologue {buf[0]/n:.0f}  "
+    print(f"{name}: workgroups {buf[3]}  per workgroup (s_memtime = shader cycles): prologue {buf[0]/n:.0f}  "
           f"K loop {buf[1]/n:.0f}  epilogue {buf[2]/n:.0f}   shares {buf[0]/tot:.2f} / {buf[1]/tot:.2f} / {buf[2]/tot:.2f}")
 
 for i, name in enumerate(names):

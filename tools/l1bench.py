@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision=sys.argv[1] if len(sys.argv) > 1 else "bf16")
 u8 = synth.synth_patches_u8(512, seed=1, device=dev)
 net.forward(u8)
-i = [n for n, _ in bench.OPS].index("l1b0c1")
+i = [n for n, _ in bench.OPS].index("l1b0")
 for _ in range(5):
     net.run_ops(u8, i, i)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
