@@ -280,41 +280,137 @@ __global__ __launch_bounds__(256) void vpass_kernel(const unsigned* __restrict__
 // 224) never straddle a strip.  The H image (1.6 GB written and read back per 50 000^2 level) no longer
 // exists: source bytes once (+7 %), D image written once.
 // ---------------------------------------------------------------------------------------
+#ifndef HIPAC_PL_ABL
+#define HIPAC_PL_ABL 0  // developer builds (wrong results): 1 = no edge columns, 2 = loads only, 4 = no loads
+#endif
+constexpr int kEdgeRows = 8;    // rows per edge batch
+constexpr int kEdgeSlots = 8;   // edge groups of a wave: left edges in slots 0-3, right edges in 4-7 (at most 3 + 3 occur)
+
+// Vertical state of ONE D column: running sums of the current block of S rows (R = sum (2t+1) p, P = sum p),
+// the previous block's R, and the accumulators of the clamped top / bottom window-row kernel.
+struct VCol {
+  unsigned a_rb, a_g, p_rb, p_g, b_rb, b_g;
+  int e0, e1, e2;
+  __device__ __forceinline__ void reset() {
+    a_rb = a_g = p_rb = p_g = b_rb = b_g = 0u;
+    e0 = e1 = e2 = 1 << 21;
+  }
+};
+
+// Feed the horizontally resampled pixel `px` (RGBX) of strip row rr (source row y) into column state `v` and write the
+// D pixels that complete: the dense row every S rows, the clamped window rows 0 / 223 after their 3S/2 rows.
+// Inside a block of S rows (t = rr mod S) a row feeds the rising half of output rr with weight 2t + 1 and the falling
+// half of output rr - 1 with 2S - 1 - 2t = 2S - (2t + 1): only R and P are kept, the falling part is 2S P - R.
+// R and B share a dword as 16-bit lanes (<= 255 * 2 S^2 < 65536; 2S P >= R in every lane: no borrow).
+template <int S>
+__device__ __forceinline__ void vcol_step(VCol& v, unsigned px, int rr, int y, int y_own, bool owned, int dcol,
+                                          const PlaneGeom& gm, const int* __restrict__ kk, int ksize, int top0, int bot0,
+                                          unsigned* __restrict__ dimg) {
+  constexpr int LOG2 = S == 8 ? 7 : (S == 4 ? 5 : 3);
+  constexpr int ECNT = 3 * S / 2;
+  const unsigned t = (unsigned)(rr % S), wa = 2 * t + 1;
+  const unsigned rb = px & 0x00ff00ffu, g = (px >> 8) & 0xffu;
+  v.a_rb += __umul24(rb, wa), v.a_g += __umul24(g, wa);
+  v.p_rb += rb, v.p_g += g;
+  if (t == S - 1) {  // output row rr_out = (y_own + rr + 1) / S - 2 completes (uniform)
+    const int rr_out = (y_own + rr + 1 - 2 * S) / S;
+    const bool emit = rr >= S && rr_out < gm.GY;  // the first block of a strip only starts the next row's rising half
+    const int row0 = S * rr_out - S / 2;
+    const bool unused = row0 < 0 || row0 + 2 * S > gm.HROWS;  // first / last dense row: never gathered
+    const unsigned tot_rb = v.b_rb + (2 * S * v.p_rb - v.a_rb), tot_g = v.b_g + (2 * S * v.p_g - v.a_g);
+    const unsigned r = ((tot_rb & 0xffffu) + S * S) >> LOG2, b = ((tot_rb >> 16) + S * S) >> LOG2;
+    const unsigned gg = (tot_g + S * S) >> LOG2;
+    if (emit && dcol >= 0)
+      dimg[(long long)rr_out * gm.HW + dcol] = unused ? 0xff000000u : (r | (gg << 8) | (b << 16) | 0xff000000u);
+    v.b_rb = v.a_rb, v.b_g = v.a_g, v.a_rb = v.a_g = v.p_rb = v.p_g = 0u;
+  }
+  // clamped window rows (top: window row 0, bottom: window row 223), general 22-bit weights
+  if (owned) {
+    const int ym = y % kLat;
+    int te = -1, iy = 0, jrow = 0;
+    if (ym >= top0 && ym < top0 + ECNT) te = ym - top0, iy = y / kLat, jrow = 0;
+    else {
+      const int yb = y - bot0;  // = 224 iy + t
+      if (yb >= 0 && yb % kLat < ECNT) te = yb % kLat, iy = yb / kLat, jrow = 223;
+    }
+    if (te >= 0 && iy < gm.NY) {
+      const int kv = kk[jrow * ksize + te];
+      v.e0 += __mul24((int)(px & 255u), kv), v.e1 += __mul24((int)((px >> 8) & 255u), kv);
+      v.e2 += __mul24((int)((px >> 16) & 255u), kv);
+      if (te == ECNT - 1) {
+        if (dcol >= 0)
+          dimg[(long long)(gm.GY + (jrow ? gm.NY : 0) + iy) * gm.HW + dcol] =
+              clip8p(v.e0) | (clip8p(v.e1) << 8) | (clip8p(v.e2) << 16) | 0xff000000u;
+        v.e0 = v.e1 = v.e2 = 1 << 21;
+      }
+    }
+  }
+}
+
+// EDGE: the wave also produces the clamped left / right window columns (j = 0, 223) of the groups that carry one
+// (group 0 / group 27 of every 28).  Only 4-6 of a wave's 64 lanes do, so the general-weight kernel (36 multiply-adds
+// per pixel) is NOT run per row under a mostly empty exec mask: the edge lanes park their raw cover in LDS, every
+// kEdgeRows rows the whole wave computes the kEdgeRows x kEdgeSlots edge pixels at once (lane = (row, slot)), and the
+// owning lanes then run the vertical step of their one edge column over those rows.  (Ablation on a 50 000^2 level: the
+// per-row form cost 1.5 ms of VALU time next to 0.75 ms for everything else and 1.6 ms of streaming.)
 template <int S, bool EDGE>
 __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, int W, int H, long long pitch,
                                              const PlaneGeom& gm, const int* __restrict__ bounds,
                                              const int* __restrict__ kk, int ksize, unsigned* __restrict__ dimg,
-                                             unsigned* __restrict__ cells, int h, bool live) {
+                                             unsigned* __restrict__ cells, int h, bool live, unsigned* __restrict__ lds_wave) {
   constexpr int CB0 = S == 8 ? 12 : (S == 4 ? 8 : 4);
   constexpr int NDW = S == 8 ? 12 : (S == 4 ? 10 : 8);
   constexpr int NOUT = 8 / S;
   constexpr int LOG2 = S == 8 ? 7 : (S == 4 ? 5 : 3);
   constexpr int OWN = 112;                 // owned rows per strip
   constexpr int GPC = kLat / 8;
-  constexpr int NC = EDGE ? NOUT + 2 : NOUT;  // output columns of a thread: dense (+ left edge, right edge)
-  constexpr int ECNT = 3 * S / 2;          // taps of the clamped edge kernels
   const int lane = threadIdx.x & 63;
   const int y_own = blockIdx.y * OWN;
   const long long cb = 24LL * h - CB0;
   const long long wbytes = 3LL * W;
   const int hm = h % GPC, win_i = h / GPC;
-  const bool is_left = live && hm == 0 && win_i < gm.NX;
+  const bool is_left = EDGE && live && hm == 0 && win_i < gm.NX;
   const int hr = h - (S * kLat / 8 - 1);
-  const bool is_right = live && hr >= 0 && hr % GPC == 0 && hr / GPC < gm.NX;
+  const bool is_right = EDGE && live && hr >= 0 && hr % GPC == 0 && hr / GPC < gm.NX;
   const int right_i = hr / GPC;
+  const bool is_edge = is_left || is_right;
   // D columns of this thread's outputs (-1: none)
-  int dcol[NC];
+  int dcol[NOUT];
 #pragma unroll
   for (int k = 0; k < NOUT; ++k) dcol[k] = live ? h * NOUT + k : -1;
+  const int ecol = is_left ? gm.G + win_i : (is_right ? gm.G + gm.NX + right_i : -1);
+  // LDS slot of an edge lane: its rank among the wave's left (0..) / right (4..) edge lanes
+  int eslot = 0;
   if constexpr (EDGE) {
-    dcol[NOUT] = is_left ? gm.G + win_i : -1;
-    dcol[NOUT + 1] = is_right ? gm.G + gm.NX + right_i : -1;
+    const unsigned long long ml = __ballot(is_left), mr = __ballot(is_right);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    eslot = is_left ? __popcll(ml & below) : 4 + __popcll(mr & below);
+    eslot &= kEdgeSlots - 1;
   }
+  unsigned* const raw = lds_wave;                                      // [kEdgeRows][kEdgeSlots][NDW]
+  unsigned* const epx = lds_wave + kEdgeRows * kEdgeSlots * NDW;       // [kEdgeRows][kEdgeSlots]
 
-  unsigned a_rb[NC], a_g[NC], p_rb[NC], p_g[NC], b_rb[NC], b_g[NC];  // this block's R and P sums; previous block's R
-  int e0[NC], e1[NC], e2[NC];                                         // clamped top / bottom row kernel
+  VCol vc[NOUT];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) a_rb[c] = a_g[c] = p_rb[c] = p_g[c] = b_rb[c] = b_g[c] = 0u, e0[c] = e1[c] = e2[c] = 1 << 21;
+  for (int c = 0; c < NOUT; ++c) vc[c].reset();
+  // the vertical state of the edge column is touched once per batch: it lives in LDS between batches (9 VGPRs = one
+  // wave per SIMD of occupancy at S = 8)
+#ifndef HIPAC_PL_VE_LDS
+#define HIPAC_PL_VE_LDS 0  // 1: the edge column's vertical state lives in LDS between batches (measured: no register gain)
+#endif
+  VCol* const ve_home = reinterpret_cast<VCol*>(epx + kEdgeRows * kEdgeSlots) + eslot;
+#if HIPAC_PL_VE_LDS
+  if constexpr (EDGE) {
+    if (is_edge) {
+      VCol z;
+      z.reset();
+      *ve_home = z;
+    }
+  }
+#else
+  VCol ve;
+  ve.reset();
+#endif
   unsigned gsum = 0;
   const int top0 = bounds[0], bot0 = bounds[2 * 223];  // first source row (relative to the window) of the edge kernels
   auto load_row = [&](int rr, unsigned (&d)[NDW]) {
@@ -346,10 +442,16 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
       }
     }
   };
+  auto is_owned = [&](int rr) { return rr >= S / 2 && rr < S / 2 + OWN && y_own - S / 2 + rr < gm.HROWS; };
   auto process_row = [&](int rr, const unsigned (&d)[NDW]) {
     const int y = y_own - S / 2 + rr;
-    // ---- horizontal pass of this row: the thread's pixels, RGBX ----
-    unsigned px[NC];
+    const bool owned = is_owned(rr);
+    // whiteness sums over the OWNED rows only (halo rows belong to the neighbouring strips)
+    if (live && owned) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gsum = __builtin_amdgcn_sad_u8(d[CB0 / 4 + k], 0u, gsum);
+    }
+    // horizontal pass of this row: the thread's dense pixels, RGBX, each straight into its column's vertical step
     static_for<NOUT>([&](auto K) {
       constexpr int k = decltype(K)::value;
       unsigned p = 0xff000000u;
@@ -363,79 +465,93 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
         });
         p |= ((S * S + x) >> LOG2) << (8 * ch);
       });
-      px[k] = p;
+      vcol_step<S>(vc[k], p, rr, y, y_own, owned, dcol[k], gm, kk, ksize, top0, bot0, dimg);
     });
-    if constexpr (EDGE) {
-      // (one merged per-lane chain with the lane's weights in registers was measured: 2.55 vs 2.46 ms at P = 1792
-      // -- the 12 weight registers cost a wave of occupancy -- 2.02 vs 2.18 at 896, 2.86 vs 2.68 at 448)
-      px[NOUT] = px[NOUT + 1] = 0u;
-      if (is_left) px[NOUT] = edge_pixel<S, 0>(d, kk);
-      if (is_right) px[NOUT + 1] = edge_pixel<S, 8 - 3 * S / 2>(d, kk + 223 * ksize);
-    }
-    // whiteness sums over the OWNED rows only (halo rows belong to the neighbouring strips)
-    const bool owned = rr >= S / 2 && rr < S / 2 + OWN && y < gm.HROWS;
-    if (live && owned) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) gsum = __builtin_amdgcn_sad_u8(d[CB0 / 4 + k], 0u, gsum);
-    }
-    // ---- vertical pass, interior rows.  Inside a block of S rows (t = rr mod S) the row feeds the rising half
-    // of output rr with weight 2t + 1 and the falling half of output rr - 1 with 2S - 1 - 2t = 2S - (2t + 1):
-    // so only R = sum (2t + 1) p_t (one 24-bit mad) and P = sum p_t are kept, the falling part is 2S P - R.
-    // R and B share a dword as 16-bit lanes (<= 255 * 2 S^2 < 65536; 2S P >= R in every lane: no borrow).
-    const unsigned t = (unsigned)(rr % S), wa = 2 * t + 1;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const unsigned rb = px[c] & 0x00ff00ffu, g = (px[c] >> 8) & 0xffu;
-      a_rb[c] += __umul24(rb, wa), a_g[c] += __umul24(g, wa);
-      p_rb[c] += rb, p_g[c] += g;
-    }
-    if (t == S - 1) {  // output row rr_out = (y_own + rr + 1) / S - 2 completes (uniform)
-      const int rr_out = (y_own + rr + 1 - 2 * S) / S;
-      const bool emit = rr >= S && rr_out < gm.GY;  // the first block of a strip only starts the next row's rising half
-      const int row0 = S * rr_out - S / 2;
-      const bool unused = row0 < 0 || row0 + 2 * S > gm.HROWS;  // first / last dense row: never gathered
-      unsigned* drow = dimg + (long long)rr_out * gm.HW;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const unsigned tot_rb = b_rb[c] + (2 * S * p_rb[c] - a_rb[c]), tot_g = b_g[c] + (2 * S * p_g[c] - a_g[c]);
-        const unsigned r = ((tot_rb & 0xffffu) + S * S) >> LOG2, b = ((tot_rb >> 16) + S * S) >> LOG2;
-        const unsigned gg = (tot_g + S * S) >> LOG2;
-        if (emit && dcol[c] >= 0) drow[dcol[c]] = unused ? 0xff000000u : (r | (gg << 8) | (b << 16) | 0xff000000u);
-        b_rb[c] = a_rb[c], b_g[c] = a_g[c], a_rb[c] = a_g[c] = p_rb[c] = p_g[c] = 0u;
-      }
-    }
-    // ---- vertical pass, clamped window rows (top: window row 0, bottom: window row 223) ----
-    if (owned) {
-      const int ym = y % kLat;
-      int te = -1, iy = 0, jrow = 0;
-      if (ym >= top0 && ym < top0 + ECNT) te = ym - top0, iy = y / kLat, jrow = 0;
-      else {
-        const int yb = y - bot0;  // = 224 iy + t
-        if (yb >= 0 && yb % kLat < ECNT) te = yb % kLat, iy = yb / kLat, jrow = 223;
-      }
-      if (te >= 0 && iy < gm.NY) {
-        const int kv = kk[jrow * ksize + te];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          e0[c] += __mul24((int)(px[c] & 255u), kv), e1[c] += __mul24((int)((px[c] >> 8) & 255u), kv);
-          e2[c] += __mul24((int)((px[c] >> 16) & 255u), kv);
-        }
-        if (te == ECNT - 1) {
-          unsigned* drow = dimg + (long long)(gm.GY + (jrow ? gm.NY : 0) + iy) * gm.HW;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            if (dcol[c] >= 0) drow[dcol[c]] = clip8p(e0[c]) | (clip8p(e1[c]) << 8) | (clip8p(e2[c]) << 16) | 0xff000000u;
-            e0[c] = e1[c] = e2[c] = 1 << 21;
-          }
-        }
-      }
-    }
   };
-  // (a 3-deep register ring of prefetched rows was measured slower: 145 VGPRs, one wave per SIMD fewer)
-  for (int rr = 0; rr < OWN + S; ++rr) {
-    unsigned d[NDW];
-    load_row(rr, d);
+  // Prefetch (S = 2 only): row rr + 1 is requested before row rr is processed -- two register sets, the inner loop
+  // unrolled by 2 so that they alternate.  Measured on a 50 000^2 level: 448-pixel windows 3.29 -> 2.99 ms, but 1792
+  // 2.27 -> 2.48 (the registers cost occupancy) and 896 +-0; a 3-deep ring was slower everywhere.
+#ifndef HIPAC_PL_PREFETCH
+#define HIPAC_PL_PREFETCH -1  // -1: by window size, 0 / 1: force
+#endif
+  constexpr bool PF = HIPAC_PL_PREFETCH < 0 ? S == 2 : HIPAC_PL_PREFETCH != 0;
+  unsigned dbuf[PF ? 2 : 1][NDW];
+  if constexpr (PF && !(HIPAC_PL_ABL & 4)) load_row(0, dbuf[0]);
+  // one row: BUF = register set holding it (compile-time, so the two sets never need dynamic indexing)
+  auto row_body = [&](int rb, int i, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    const int rr = rb + i;
+    unsigned(&d)[NDW] = dbuf[buf];
+#if HIPAC_PL_ABL & 4
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) d[k] = 0x01020304u * (unsigned)(rr + k + lane);
+#else
+    if constexpr (PF) {
+      if (rr + 1 < OWN + S) load_row(rr + 1, dbuf[PF ? 1 - buf : 0]);
+    } else {
+      load_row(rr, d);
+    }
+#endif
+#if HIPAC_PL_ABL & 2
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) gsum += d[k];
+#else
     process_row(rr, d);
+    if constexpr (EDGE && !(HIPAC_PL_ABL & 1)) {
+      if (is_edge) {  // park the raw cover of this row
+        unsigned* dst = raw + (i * kEdgeSlots + eslot) * NDW;
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) dst[k] = d[k];
+      }
+    }
+#endif
+  };
+  static_assert((OWN + S) % 2 == 0 && kEdgeRows % 2 == 0, "rows are walked in pairs");
+  for (int rb = 0; rb < OWN + S; rb += kEdgeRows) {
+    if constexpr (PF) {
+#pragma unroll 1
+      for (int i = 0; i < kEdgeRows; i += 2) {
+        if (rb + i >= OWN + S) break;
+        row_body(rb, i, std::integral_constant<int, 0>{});
+        row_body(rb, i + 1, std::integral_constant<int, 1>{});
+      }
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < kEdgeRows; ++i) {
+        if (rb + i >= OWN + S) break;
+        row_body(rb, i, std::integral_constant<int, 0>{});
+      }
+    }
+#if !(HIPAC_PL_ABL & 3)
+    if constexpr (EDGE) {
+      __builtin_amdgcn_wave_barrier();
+      {  // the wave's kEdgeRows x kEdgeSlots edge pixels, one per lane (unused slots compute on stale bytes; never read)
+        const int e = lane & (kEdgeSlots - 1);
+        unsigned dd[NDW];
+        const unsigned* src = raw + lane * NDW;  // = (row lane / kEdgeSlots, slot e)
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) dd[k] = src[k];
+        const unsigned px = e < 4 ? edge_pixel<S, 0>(dd, kk) : edge_pixel<S, 8 - 3 * S / 2>(dd, kk + 223 * ksize);
+        epx[lane] = px;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (is_edge) {  // vertical step of this lane's edge column over the batch's rows
+#if HIPAC_PL_VE_LDS
+        VCol ve = *ve_home;
+#endif
+        for (int i = 0; i < kEdgeRows; ++i) {
+          const int rr = rb + i;
+          if (rr >= OWN + S) break;
+          vcol_step<S>(ve, epx[i * kEdgeSlots + eslot], rr, y_own - S / 2 + rr, y_own, is_owned(rr), ecol, gm, kk, ksize, top0,
+                       bot0, dimg);
+        }
+#if HIPAC_PL_VE_LDS
+        *ve_home = ve;
+#endif
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#endif
   }
   // cell sums: segmented reduction over the lanes of a wave that share a cell column
   const int cx = live ? h / GPC : -1 - lane;
@@ -449,25 +565,40 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
   if (live && (lane == 63 || cnext != cx)) atomicAdd(&cells[(y_own / kLat) * gm.NCX + cx], gsum);
 }
 
+#ifndef HIPAC_PL_WAVES
+#define HIPAC_PL_WAVES 0
+#endif
 template <int S>
-__global__ __launch_bounds__(256) void planes_kernel(const uint8_t* __restrict__ level, int W, int H, long long pitch,
+__global__ __launch_bounds__(256)
+#if HIPAC_PL_WAVES
+__attribute__((amdgpu_waves_per_eu(HIPAC_PL_WAVES, HIPAC_PL_WAVES)))
+#endif
+void planes_kernel(const uint8_t* __restrict__ level, int W, int H, long long pitch,
                                                      PlaneGeom gm, const int* __restrict__ bounds,
                                                      const int* __restrict__ kk, int ksize,
                                                      unsigned* __restrict__ dimg, unsigned* __restrict__ cells,
                                                      int n_edge_waves) {
   constexpr int GPC = kLat / 8;
+  constexpr int NDW = S == 8 ? 12 : (S == 4 ? 10 : 8);
+  constexpr int LDS_WAVE = kEdgeRows * kEdgeSlots * (NDW + 1) + kEdgeSlots * 12;  // dwords: parked covers, edge pixels, edge column states
+  __shared__ unsigned lds_edge[4 * LDS_WAVE];
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform by construction
-  if (n_edge_waves < 0) {  // natural order: every wave carries its 4-5 edge groups (measured faster, see the launch)
+  unsigned* const lds_wave = lds_edge + (threadIdx.x >> 6) * LDS_WAVE;
+  if (n_edge_waves < 0) {  // natural order: every wave carries its 4-6 edge groups (measured faster, see the launch)
     const int h = wave * 64 + lane;
-    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+#if HIPAC_PL_ABL & 1
+    planes_strip<S, false>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP, lds_wave);  // no edge columns
+    return;
+#endif
+    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP, lds_wave);
   } else if (__builtin_amdgcn_readfirstlane(wave) < n_edge_waves) {
     const int e = wave * 64 + lane;                       // edge group index: (window column, left | right)
     const int h = (e >> 1) * GPC + ((e & 1) ? GPC - 1 : 0);
-    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+    planes_strip<S, true>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP, lds_wave);
   } else {
     const int j = (wave - n_edge_waves) * 64 + lane;      // interior group index: 26 of every 28
     const int h = (j / (GPC - 2)) * GPC + 1 + j % (GPC - 2);
-    planes_strip<S, false>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP);
+    planes_strip<S, false>(level, W, H, pitch, gm, bounds, kk, ksize, dimg, cells, h, h < gm.NGRP, lds_wave);
   }
 }
 
