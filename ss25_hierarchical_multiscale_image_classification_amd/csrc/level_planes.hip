@@ -476,7 +476,6 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
 #endif
   constexpr bool PF = HIPAC_PL_PREFETCH < 0 ? S == 2 : HIPAC_PL_PREFETCH != 0;
   unsigned dbuf[PF ? 2 : 1][NDW];
-  if constexpr (PF && !(HIPAC_PL_ABL & 4)) load_row(0, dbuf[0]);
   // one row: BUF = register set holding it (compile-time, so the two sets never need dynamic indexing)
   auto row_body = [&](int rb, int i, auto BUF) {
     constexpr int buf = decltype(BUF)::value;
@@ -487,7 +486,9 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
     for (int k = 0; k < NDW; ++k) d[k] = 0x01020304u * (unsigned)(rr + k + lane);
 #else
     if constexpr (PF) {
-      if (rr + 1 < OWN + S) load_row(rr + 1, dbuf[PF ? 1 - buf : 0]);
+      // no request is in flight across the edge batch (its registers would add to the batch's peak): a block's first
+      // row is requested at the top of the block
+      if (rr + 1 < OWN + S && i + 1 < kEdgeRows) load_row(rr + 1, dbuf[PF ? 1 - buf : 0]);
     } else {
       load_row(rr, d);
     }
@@ -509,6 +510,7 @@ __device__ __forceinline__ void planes_strip(const uint8_t* __restrict__ level, 
   static_assert((OWN + S) % 2 == 0 && kEdgeRows % 2 == 0, "rows are walked in pairs");
   for (int rb = 0; rb < OWN + S; rb += kEdgeRows) {
     if constexpr (PF) {
+      if constexpr (!(HIPAC_PL_ABL & 4)) load_row(rb, dbuf[0]);
 #pragma unroll 1
       for (int i = 0; i < kEdgeRows; i += 2) {
         if (rb + i >= OWN + S) break;
