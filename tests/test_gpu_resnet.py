@@ -11,7 +11,7 @@ named type, so the error is rounding only:
 north_star's 1e-3 (fp32-relative) is met with three orders of magnitude to spare by the fp32
 mode and ENFORCED here for the fp16 features.  The fp16 LOGITS sit at the bound (0.8-1.3e-3 depending on
 the patch set): the fc output cancels (|logit| << sum |w_i f_i|), so the same absolute feature error is
-a ~2x larger relative logit error.  tools/prec_sites.py shows why no 16-bit operand format does better at
+a ~2x larger relative logit error.  tests/tools/prec_sites.py shows why no 16-bit operand format does better at
 full MFMA rate: each of the ~40 rounding sites (20 weight tensors, 20 activation tensors) alone moves the
 logits by 1.5-4e-4 and they add in quadrature; an fp32 residual stream removes 8 half-sites (-5 %).
 bf16 (the BASELINE dtype, the one benchmarked) cannot meet 1e-3 by construction (8-bit mantissa).

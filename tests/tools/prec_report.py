@@ -1,7 +1,7 @@
 """Developer tool (GPU box): measured error of each precision mode against the fp32 oracle on the
 golden patches + 24 random patches, and the throughput of the fp32 parity mode."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import resnet18_ref as R, transform_ref as T
 from ss25_hierarchical_multiscale_image_classification_amd import capi, synth

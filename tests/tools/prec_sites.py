@@ -1,5 +1,5 @@
 import sys, torch, numpy as np, torch.nn.functional as F
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import resnet18_ref as R, transform_ref as T
 from ss25_hierarchical_multiscale_image_classification_amd import synth
 torch.set_num_threads(8)
