@@ -155,11 +155,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int g = tid % c4, rsub = tid / c4;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (rsub < rows_per_pass) {
-    for (long long r = (long long)blockIdx.x * rows_per_pass + rsub; r < M; r += (long long)gridDim.x * rows_per_pass) {
-      const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * g);
+    auto add = [&](const float4& v) {
       s[0] += v.x, s[1] += v.y, s[2] += v.z, s[3] += v.w;
       q[0] += (double)v.x * v.x, q[1] += (double)v.y * v.y, q[2] += (double)v.z * v.z, q[3] += (double)v.w * v.w;
+    };
+    const long long step = (long long)gridDim.x * rows_per_pass;
+    long long r = (long long)blockIdx.x * rows_per_pass + rsub;
+    for (; r + 3 * step < M; r += 4 * step) {  // four rows in flight per thread: the pass is a pure HBM stream
+      const float4 v0 = *reinterpret_cast<const float4*>(x + r * C + 4 * g);
+      const float4 v1 = *reinterpret_cast<const float4*>(x + (r + step) * C + 4 * g);
+      const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2 * step) * C + 4 * g);
+      const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3 * step) * C + 4 * g);
+      add(v0), add(v1), add(v2), add(v3);
     }
+    for (; r < M; r += step) add(*reinterpret_cast<const float4*>(x + r * C + 4 * g));
   }
   __shared__ double red[2][256][4];
 #pragma unroll
@@ -225,16 +234,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (rsub < rows_per_pass) {
     const float4 m = *reinterpret_cast<const float4*>(mean + 4 * g), r = *reinterpret_cast<const float4*>(rstd + 4 * g);
-    for (long long row = (long long)blockIdx.x * rows_per_pass + rsub; row < M; row += (long long)gridDim.x * rows_per_pass) {
-      float4 d = *reinterpret_cast<const float4*>(dy + row * C + 4 * g);
-      const float4 v = *reinterpret_cast<const float4*>(x + row * C + 4 * g);
-      if (ymask) {
-        const float4 k = *reinterpret_cast<const float4*>(ymask + row * C + 4 * g);
-        d.x = k.x > 0.f ? d.x : 0.f, d.y = k.y > 0.f ? d.y : 0.f, d.z = k.z > 0.f ? d.z : 0.f, d.w = k.w > 0.f ? d.w : 0.f;
-      }
+    auto add = [&](float4 d, const float4& v, const float4& k) {
+      if (ymask) d.x = k.x > 0.f ? d.x : 0.f, d.y = k.y > 0.f ? d.y : 0.f, d.z = k.z > 0.f ? d.z : 0.f, d.w = k.w > 0.f ? d.w : 0.f;
       s[0] += d.x, s[1] += d.y, s[2] += d.z, s[3] += d.w;
       q[0] += (double)d.x * ((v.x - m.x) * r.x), q[1] += (double)d.y * ((v.y - m.y) * r.y);
       q[2] += (double)d.z * ((v.z - m.z) * r.z), q[3] += (double)d.w * ((v.w - m.w) * r.w);
+    };
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    const long long step = (long long)gridDim.x * rows_per_pass;
+    long long row = (long long)blockIdx.x * rows_per_pass + rsub;
+    for (; row + step < M; row += 2 * step) {  // two rows (4-6 loads) in flight per thread
+      const long long o0 = row * C + 4 * g, o1 = (row + step) * C + 4 * g;
+      const float4 d0 = *reinterpret_cast<const float4*>(dy + o0), d1 = *reinterpret_cast<const float4*>(dy + o1);
+      const float4 v0 = *reinterpret_cast<const float4*>(x + o0), v1 = *reinterpret_cast<const float4*>(x + o1);
+      const float4 k0 = ymask ? *reinterpret_cast<const float4*>(ymask + o0) : one;
+      const float4 k1 = ymask ? *reinterpret_cast<const float4*>(ymask + o1) : one;
+      add(d0, v0, k0), add(d1, v1, k1);
+    }
+    for (; row < M; row += step) {
+      const long long o0 = row * C + 4 * g;
+      add(*reinterpret_cast<const float4*>(dy + o0), *reinterpret_cast<const float4*>(x + o0),
+          ymask ? *reinterpret_cast<const float4*>(ymask + o0) : one);
     }
   }
   __shared__ double red[2][256][4];
@@ -691,7 +711,7 @@ static int bn_forward(const BnCtx& c, int i, int n, const float* resid, int relu
   HIPAC_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * 512 * 8, c.s));
   const int rows_per_pass = 256 / (d.cout / 4);
   long long gs = (M + rows_per_pass - 1) / rows_per_pass;
-  if (gs > 2048) gs = 2048;
+  if (gs > 512) gs = 512;  // 2 workgroups per CU: every workgroup ends in 2 C fp64 atomics on the same C addresses
   hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, x, M, d.cout, sums);
   float* rm = c.stats ? c.stats + stat_offset(i) : nullptr;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((d.cout + 255) / 256), dim3(256), 0, c.s, (const double*)sums, M, d.cout, c.eps,
@@ -716,7 +736,7 @@ static int bn_backward(const BnCtx& c, int i, int n, const float* dy, const floa
   HIPAC_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * 512 * 8, c.s));
   const int rows_per_pass = 256 / (d.cout / 4);
   long long gs = (M + rows_per_pass - 1) / rows_per_pass;
-  if (gs > 2048) gs = 2048;
+  if (gs > 512) gs = 512;  // 2 workgroups per CU: every workgroup ends in 2 C fp64 atomics on the same C addresses
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, dy, x, ymask, M, d.cout, mean, rstd, sums);
   const long long n4 = M * d.cout / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, c.s, dy, x, ymask, dx, n4, M, d.cout, mean, rstd,
