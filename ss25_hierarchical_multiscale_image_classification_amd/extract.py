@@ -18,7 +18,7 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import capi, synth
+from . import capi, synth, trace
 
 PATCH_SIZES = {0: 1792, 1: 896, 2: 448, 3: 224}  # src/main.py:614
 LABEL_NAMES = {0: "normal", 1: "tumor"}  # src/datasets/patch_dataset.py:15
@@ -352,10 +352,11 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
             while mk[mi][0] < end:
                 mi += 1
             main.wait_event(mk[mi][1])
-            out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
+            with trace.span(f"resnet18 forward [{lo}:{end})"):
+                out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
             lo = end
 
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), trace.span("window decisions, small levels"):
         lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in small]
         kepts = [lw.kept_index() for lw in lws]  # host syncs with the side stream only
     n_small = sum(int(k.shape[0]) for k in kepts)
@@ -373,7 +374,7 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
             for lw, k in zip(lws, kepts):
                 done = gather_into(buf_s, done, lw, k, mk_s)
         forward_range(buf_s, mk_s, 0, n_small - carry)  # full batches; the remainder joins the big level
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), trace.span(f"window decisions, level {big}"):
         lwb = LevelWindows(slide, big, stride_of(big))
         kb = lwb.kept_index()
     nb = int(kb.shape[0])

@@ -150,3 +150,31 @@ def test_froc_csv_is_what_the_reference_reader_parses(tmp_path):
     assert abs(probs[0] - 0.119203) < 1e-5 and abs(probs[1] - 0.880797) < 1e-5 and abs(probs[2] - 0.5) < 1e-6
     # window centres in level-0 pixels: level 0 window 1792 -> (896, 896); level 1 (224,448)+448 -> x2; level 3 +112 -> x8
     assert (xs, ys) == ([896, (224 + 448) * 2, 112 * 8], [896, (448 + 448) * 2, (224 + 112) * 8])
+
+
+def test_trace_span_is_a_no_op_without_the_env_and_balanced_with_it(monkeypatch):
+    """trace.span: nothing is loaded or called unless HIPAC_ROCTX=1; with it every push has its pop (checked on a
+    stand-in library object, the real roctx library is only present on ROCm boxes)."""
+    from ss25_hierarchical_multiscale_image_classification_amd import trace
+
+    monkeypatch.delenv("HIPAC_ROCTX", raising=False)
+    monkeypatch.setattr(trace, "_lib", lambda: (_ for _ in ()).throw(AssertionError("library touched")))
+    with trace.span("x"):
+        pass
+    calls = []
+
+    class Fake:
+        def roctxRangePushA(self, name):
+            calls.append(("push", name))
+
+        def roctxRangePop(self):
+            calls.append(("pop",))
+
+    monkeypatch.setenv("HIPAC_ROCTX", "1")
+    monkeypatch.setattr(trace, "_lib", lambda: Fake())
+    try:
+        with trace.span("window decisions"):
+            raise ValueError("inside")
+    except ValueError:
+        pass
+    assert calls == [("push", b"window decisions"), ("pop",)]
