@@ -146,22 +146,24 @@ def test_uint8_table_kernel_equals_normalize_then_forward_bitwise(monkeypatch):
         net.forward(torch.zeros((2, 200, 224, 3), dtype=torch.uint8, device="cuda"))
 
 
-@pytest.mark.parametrize("n", [1, 7, 70])
+@pytest.mark.parametrize("n", [1, 7, 9, 70, 520])
 def test_layer1_fused_block_equals_separate_convs_bitwise(monkeypatch, n):
     """Default: a layer1 BasicBlock is ONE kernel (conv1 -> I rows in LDS -> conv2 + shortcut, block_c64.h).
     HIPAC_L1_FUSED=0 launches conv1 and conv2 separately (conv3x3_c64_kernel).  Same MFMA order, same
     roundings: both block outputs and everything after them agree bit for bit -- at one image (4 strips,
-    28 idle workgroups per 32), at 7 (not a multiple of the 8 XCDs) and at 70 (workgroups walk several strips)."""
+    28 idle workgroups per 32), at 7 and 9 (not multiples of the 8 XCDs), at 70 (workgroups walk several strips) and
+    at 520 (two sub-batches: 512 + 8)."""
     sd = synth.seeded_resnet18_state_dict(4, num_classes=2)
     u8 = _border_patches(max(n, 3), 30 + n)[:n].cuda()
     for prec in ("bf16", "fp16"):
         net = capi.PackedResNet18(sd, precision=prec)
         monkeypatch.setenv("HIPAC_L1_FUSED", "0")
         f0, l0, _ = net.forward(u8, want_logits=True)
-        taps0 = [net.tap(n, t).clone() for t in (2, 3)]
+        tap_ids = (2, 3) if n <= 512 else ()  # the taps address one sub-batch; 520 patches = two (512 + 8)
+        taps0 = [net.tap(n, t).clone() for t in tap_ids]
         monkeypatch.setenv("HIPAC_L1_FUSED", "1")
         f1, l1, _ = net.forward(u8, want_logits=True)
-        for t, ref in zip((2, 3), taps0):
+        for t, ref in zip(tap_ids, taps0):
             got = net.tap(n, t)
             assert torch.equal(got, ref), f"{prec} layer1 block {t - 2}: max diff {(got - ref).abs().max().item()}"
         assert torch.equal(f0, f1) and torch.equal(l0, l1)
