@@ -23,7 +23,7 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / os.environ.get("HIPAC_OBJ_DIR", "build")
 LIB = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")
 SOURCES = ["hipac_capi.hip", "preprocess.hip", "level_planes.hip", "mil.hip", "ntxent.hip", "conv_bf16.hip", "conv_f16.hip",
-           "conv_f32.hip", "train.hip"]
+           "conv_f32.hip", "conv_f16x3.hip", "train.hip"]
 HEADERS = ["common.h", "conv_igemm.h", "block_c64.h", "../../include/hipac.h"]
 ARCH = "gfx950"
 # -ffp-contract=off: the host-side Pillow coefficient restatement must round every
@@ -68,7 +68,7 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(compile_one, jobs))
     objs = [OBJ / (Path(src).stem + ".o") for src in SOURCES]
     if force or jobs or _stale(LIB, objs):

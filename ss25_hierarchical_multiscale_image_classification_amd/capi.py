@@ -19,14 +19,16 @@ import torch
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")  # override: A/B builds of the same ABI
 
-PREC_BF16, PREC_FP16, PREC_FP32 = 0, 1, 2
+PREC_BF16, PREC_FP16, PREC_FP32, PREC_FP16X3 = 0, 1, 2, 3
 IN_NCHW_F32, IN_NHWC4_PAD, IN_U8_HWC = 0, 1, 2
 OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
 PATCH, PAD_H, PAD_W = 224, 230, 232
+ABI_VERSION = 3  # include/hipac.h HIPAC_ABI_VERSION this binding was written against
 
-# "fp32" is the parity mode: fp32 storage and the exact f32 MFMA (about 1/16 of the bf16 rate)
-PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16, "fp32": PREC_FP32}
-TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16, PREC_FP32: torch.float32}
+# "fp16x3" is the parity mode (fp16 (hi, lo) pairs, three MFMA products per term: the reference's fp32 results to 1e-3);
+# "fp32" the debugging reference: fp32 storage and the exact f32 MFMA (about 1/16 of the bf16 rate)
+PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16, "fp32": PREC_FP32, "fp16x3": PREC_FP16X3}
+TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16, PREC_FP32: torch.float32, PREC_FP16X3: torch.float32}
 
 
 class HipacError(RuntimeError):
@@ -140,8 +142,8 @@ def load_library(path: Optional[os.PathLike] = None):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.hipac_abi_version() != 1:
-            raise HipacError(f"ABI version mismatch: {lib.hipac_abi_version()}")
+        if lib.hipac_abi_version() != ABI_VERSION:
+            raise HipacError(f"ABI version mismatch: library {lib.hipac_abi_version()}, binding {ABI_VERSION}")
         if path is None:
             _lib = lib
         return lib

@@ -103,6 +103,7 @@ struct Net {
   float* fc_b;
   char* zero_page;  // device, 256 zero bytes: DMA source for out-of-image conv taps
   unsigned short* lut_t;  // device, T[3][256]: (v/255 - mean)/std in fp32, rounded to T (uint8 input path)
+  float* lut_f32;         // device, float[3][256]: the same table unrounded (fp16x3 mode, uint8 input)
 };
 
 // Workspace plan.  The trunk runs in two phases so every launch fills the chip:
@@ -111,7 +112,7 @@ struct Net {
 // Offsets are bytes into the caller's workspace; T = 2-byte element.
 struct Plan {
   int bc, gc;
-  int esz;        // bytes per activation element: 2 (bf16 / fp16) or 4 (fp32 parity mode)
+  int esz;        // bytes per activation element: 2 (bf16 / fp16) or 4 (fp32 parity mode; fp16x3: one (hi, lo) pair)
   int u8_input;   // 1: the stem reads raw uint8 HWC patches (normalise fused); needs fuse_stem
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   int stem_strip; // uint8 input: 1 = strip kernel (default), 0 = tile kernel with the LDS table (first form)
@@ -142,6 +143,9 @@ int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int 
                   hipStream_t s, int first, int last);
 int run_trunk_f32(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                   hipStream_t s, int first, int last);
+int run_trunk_f16x3(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                    hipStream_t s, int first, int last);
+int launch_u8_to_nhwc4_f32(const unsigned char* x, const float* lut, float* out, int n, hipStream_t s);
 
 // elementwise.hip
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);

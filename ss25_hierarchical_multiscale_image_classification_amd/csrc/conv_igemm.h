@@ -251,8 +251,35 @@ __device__ __forceinline__ void wait_vmcnt() {
 // exactly the centre tap of this convolution, so it rides along as CC extra K tiles (centre-tap
 // activation tile x projection weights) into a second accumulator set and leaves through a
 // second epilogue (bias only, no ReLU) into `outp_p`: one launch, one pass over the input.
+//
+// SPLIT (precision fp16x3, the mode that meets the reference's fp32 results to 1e-3): every value is the PAIR
+// hi = rn16(v), lo = rn16(v - hi) of fp16 numbers.  Activations are stored [pixel][hi: CIN | lo: CIN] (2 CIN
+// elements per pixel), weights [Cout][tap][3 CIN] as per-64-channel triples (hi_c | lo_c | hi_c), and the GEMM
+// runs over 3 CIN "virtual" channels: virtual chunk v = 3c + j reads activation chunk c of the hi plane (j = 0, 1)
+// or of the lo plane (j = 2): D = Whi Xhi + Wlo Xhi + Whi Xlo on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+// (the dropped lo x lo term is 2^-22 relative).  The epilogue splits its fp32 result into a pair again.
+template <bool SPLIT, int CC>
+__device__ __forceinline__ constexpr int split_achunk(int v) {  // activation chunk (in units of 64 channels) of virtual chunk v
+  return SPLIT ? ((v % 3 == 2) ? CC + v / 3 : v / 3) : v;
+}
+// fp32 -> (hi, lo) pair of fp16 fragments
+__device__ __forceinline__ void split_pair8(const float* v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+__device__ __forceinline__ void split_pair4(const float* v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
-          bool RELU, bool RESID, bool OUTF32, bool PROJ = false>
+          bool RELU, bool RESID, bool OUTF32, bool PROJ = false, bool SPLIT = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kernel(
     const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
     const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page,
@@ -263,11 +290,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   constexpr int PAD = KS / 2;
   constexpr int HO = (HI + 2 * PAD - KS) / STRIDE + 1;
   constexpr int WO = (WI + 2 * PAD - KS) / STRIDE + 1;
-  constexpr int CC = CIN / 64;
+  constexpr int RC = CIN / 64;                      // real 64-channel chunks
+  constexpr int CC = SPLIT ? 3 * RC : RC;           // (virtual) chunks of the K loop
+  constexpr int PIXC = SPLIT ? 2 * CIN : CIN;       // activation elements per input pixel
+  constexpr int OPIX = SPLIT ? 2 * COUT : COUT;     // elements per output pixel (T outputs)
   constexpr int KT = KS * KS * CC;
   constexpr int KTOT = KT * 64;
   constexpr int KTP = PROJ ? KT + CC : KT;          // + the projection's K tiles
   static_assert(!PROJ || (KS == 3 && STRIDE == 2 && !RESID && !OUTF32), "projection rides on 3x3/2 only");
+  static_assert(!SPLIT || (std::is_same<T, _Float16>::value && !RESID), "split pairs are fp16");
   constexpr int WM = BM / 64, WN = BN / 64, NWAVES = WM * WN;
   constexpr int APW = BM / 8 / NWAVES;  // 1-KiB A pieces per wave per K tile
   constexpr int WPW = BN / 8 / NWAVES;  // 1-KiB W pieces per wave per K tile
@@ -311,7 +342,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
     const int rem = mm - b * (HO * WO);
     const int oh = rem / WO, ow = rem - oh * WO;
     const int ih0 = oh * STRIDE - PAD, iw0 = ow * STRIDE - PAD;
-    a_off[i] = (((b * HI + ih0) * WI + iw0) * CIN + schunk * 8) * 2;
+    a_off[i] = (((b * HI + ih0) * WI + iw0) * PIXC + schunk * 8) * 2;
     unsigned mask = 0;
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh)
@@ -327,7 +358,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
     const int row = (wave + NWAVES * i) * 8 + prow;  // row inside the BN tile
     const int schunk = dchunk ^ ((row >> 1) & 7);
     w_off[i] = ((n0 + row) * KTOT + schunk * 8) * 2;
-    if constexpr (PROJ) wp_off[i] = ((n0 + row) * CIN + schunk * 8) * 2;
+    if constexpr (PROJ) wp_off[i] = ((n0 + row) * (CC * 64) + schunk * 8) * 2;
   }
   const char* in_b = reinterpret_cast<const char*>(in);
   const char* w_b = reinterpret_cast<const char*>(wgt);
@@ -338,9 +369,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   using lptr_t = __attribute__((address_space(3))) void*;
   // LDS-DMA through buffer descriptors: a tap that leaves the image (or a row beyond M) gets an offset
   // past the descriptor's range and reads as zeros -- no zero-page select, no 64-bit address arithmetic
-  const rsrc_t in_rsrc = make_rsrc(in_b, (M / (HO * WO)) * (HI * WI * CIN * 2));
+  const rsrc_t in_rsrc = make_rsrc(in_b, (M / (HO * WO)) * (HI * WI * PIXC * 2));
   const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
-  const rsrc_t wp_rsrc = make_rsrc(PROJ ? wp_b : w_b, COUT * CIN * 2);
+  const rsrc_t wp_rsrc = make_rsrc(PROJ ? wp_b : w_b, COUT * CC * 64 * 2);
   auto issue = [&](int tap, int tapoff_bytes, int kofs_bytes, int stage, bool proj) {
     unsigned char* sbase = ring + stage * STAGE;
     static_for<APW>([&](auto I) {
@@ -379,10 +410,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   auto issue_next = [&]() __attribute__((always_inline)) {
     if (PROJ && i_t >= KT) {  // centre tap (1,1), channel chunk i_t - KT, projection weights
       const int pc = i_t - KT;
-      issue(4, ((WI + 1) * CIN + pc * 64) * 2, pc * 128, i_t % NSTAGE, true);
+      issue(4, ((WI + 1) * PIXC + split_achunk<SPLIT, RC>(pc) * 64) * 2, pc * 128, i_t % NSTAGE, true);
     } else {
       const int tap = i_kh * KS + i_kw;
-      issue(tap, ((i_kh * WI + i_kw) * CIN + i_cc * 64) * 2, i_t * 128, i_t % NSTAGE, false);
+      issue(tap, ((i_kh * WI + i_kw) * PIXC + split_achunk<SPLIT, RC>(i_cc) * 64) * 2, i_t * 128, i_t % NSTAGE, false);
       if (++i_cc == CC) {
         i_cc = 0;
         if (++i_kw == KS) {
@@ -461,12 +492,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
         for (int q = 0; q < 4; ++q) {
           const int c0 = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
           const float4 bv = *reinterpret_cast<const float4*>(bias_p + c0);
-          typename E::vec4 ov;
-          ov[0] = (T)(accp[i][j][4 * q + 0] + bv.x);
-          ov[1] = (T)(accp[i][j][4 * q + 1] + bv.y);
-          ov[2] = (T)(accp[i][j][4 * q + 2] + bv.z);
-          ov[3] = (T)(accp[i][j][4 * q + 3] + bv.w);
-          *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp_p) + (size_t)m * COUT + c0) = ov;
+          const float pv[4] = {accp[i][j][4 * q + 0] + bv.x, accp[i][j][4 * q + 1] + bv.y, accp[i][j][4 * q + 2] + bv.z,
+                               accp[i][j][4 * q + 3] + bv.w};
+          if constexpr (SPLIT) {
+            f16x4 oh, ol;
+            split_pair4(pv, oh, ol);
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp_p) + (size_t)m * OPIX + c0) = oh;
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp_p) + (size_t)m * OPIX + COUT + c0) = ol;
+          } else {
+            typename E::vec4 ov;
+            ov[0] = (T)pv[0];
+            ov[1] = (T)pv[1];
+            ov[2] = (T)pv[2];
+            ov[3] = (T)pv[3];
+            *reinterpret_cast<typename E::vec4*>(reinterpret_cast<T*>(outp_p) + (size_t)m * COUT + c0) = ov;
+          }
         }
     }
   }
@@ -502,6 +542,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
         }
         if constexpr (OUTF32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + o) = make_float4(v0, v1, v2, v3);
+        } else if constexpr (SPLIT) {
+          const float sv[4] = {v0, v1, v2, v3};
+          f16x4 oh, ol;
+          split_pair4(sv, oh, ol);
+          *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp) + (size_t)m * OPIX + c0) = oh;
+          *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp) + (size_t)m * OPIX + COUT + c0) = ol;
         } else {
           typename E::vec4 ov;
           ov[0] = (T)v0;
@@ -562,7 +608,9 @@ constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) 
 // that global traffic is 16-byte items of contiguous channel runs (residual loads and stores)
 // with no workgroup barrier; workgroups are persistent and the next tile's band is prefetched
 // behind the epilogue.
-template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32>
+// SPLIT: fp16 (hi, lo) pairs, see conv_glds_kernel; virtual chunk 3c + 1 (Wlo x Xhi) reuses the band of 3c.
+template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32,
+          bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                               const float* __restrict__ bias,
                                                               const T* __restrict__ resid, void* __restrict__ outp,
@@ -570,8 +618,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
                                                               const char* __restrict__ zero_page) {
   using E = Elem<T>;
   using frag = typename E::frag;
-  constexpr int CC = CIN / 64;
-  constexpr int KTOT = 9 * CIN;
+  constexpr int RC = CIN / 64;                      // real 64-channel chunks
+  constexpr int CC = SPLIT ? 3 * RC : RC;           // (virtual) chunks of the K loop
+  constexpr int VCIN = CC * 64;                     // K elements per tap
+  constexpr int PIXC = SPLIT ? 2 * CIN : CIN;       // activation elements per input pixel
+  constexpr int OPIX = SPLIT ? 2 * COUT : COUT;     // elements per pixel of T-typed outputs and of the residual
+  constexpr int KTOT = 9 * VCIN;
+  static_assert(!SPLIT || std::is_same<T, _Float16>::value, "split pairs are fp16");
   constexpr int WM = 2, WN = 2;                     // 4 waves: 2 pixel halves x 2 channel halves
   constexpr int MTW = BM / (WM * 32);               // 32-pixel sub-tiles per wave (2 or 4)
   constexpr int WTN = BN / WN, NT = WTN / 32;       // channels per wave, 32-wide tiles per wave
@@ -615,7 +668,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       const int mm = mstart_ + q - 2;            // flattened pixel held by this slot
       const bool ok = q >= 2 && q <= npx_ + 1 && mm >= 0 && mm < M;
       const int schunk = dchunk ^ ((q >> 1) & 7);
-      const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
+      const char* src = ok ? in_b + ((size_t)mm * PIXC + split_achunk<SPLIT, RC>(cc) * 64 + schunk * 8) * 2
+                           : zero_page + dchunk * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
     }
   };
@@ -644,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
   auto issue_w = [&](int step, int slot_) {  // weights of step = cc*9 + tap: K offset (tap*CIN + cc*64)
     const int cc = step / 9, tap = step - cc * 9;
-    const int kofs_bytes = (tap * CIN + cc * 64) * 2;
+    const int kofs_bytes = (tap * VCIN + cc * 64) * 2;
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
@@ -695,6 +749,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   const int e_px = lane / CPW;                        // pixel of item k: e_px + k * (64 / CPW)
   // residual, prefetched into registers: sub-tile 0 behind the MFMAs of the last K step,
   // sub-tile i+1 behind the staging of sub-tile i (two register sets)
+  // (SPLIT: the two register sets hold the hi and the lo fragments of ONE sub-tile, fetched at the top of that sub-tile)
   frag rv[2][RESID ? IPT : 1];
   auto load_resid = [&](auto SUB) {
     constexpr int i = decltype(SUB)::value;
@@ -703,7 +758,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
       for (int k = 0; k < IPT; ++k) {
         int m = m0 + wm * (MTW * 32) + i * 32 + e_px + k * (64 / CPW);
         m = m < M ? m : M - 1;  // unconditional load from a valid row (tail rows are never stored)
-        rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0);
+        if constexpr (SPLIT) {
+          rv[0][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * OPIX + e_c0);
+          rv[1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * OPIX + COUT + e_c0);
+        } else {
+          rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0);
+        }
       }
     }
   };
@@ -718,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 #endif
   int s = 0;
   for (int cc = 0; cc < CC; ++cc) {
-    if (cc > 0) {
+    if (cc > 0 && (!SPLIT || cc % 3 != 1)) {  // (SPLIT: chunk 3c + 1 multiplies the band of 3c by the low weight halves)
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
       issue_band(cc);
     }
@@ -739,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 #if !defined(HIPAC_ABL_NO_W_DMA) && HIPAC_HALO_W_ISSUE_KK < 0
       if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
 #endif
-      if (RESID && s == NSTEP - 1) load_resid(std::integral_constant<int, 0>{});
+      if (RESID && !SPLIT && s == NSTEP - 1) load_resid(std::integral_constant<int, 0>{});
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
@@ -821,7 +881,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   unsigned char* const Sl = Wbuf + wave * (32 * SROWW);  // this wave's private staging
   static_for<MTW>([&](auto SUB) {
     constexpr int i = decltype(SUB)::value;
-    if constexpr (i + 1 < MTW) load_resid(std::integral_constant<int, i + 1>{});
+    if constexpr (SPLIT) {
+      load_resid(std::integral_constant<int, i>{});  // lands behind the staging round trip below
+    } else if constexpr (i + 1 < MTW) {
+      load_resid(std::integral_constant<int, i + 1>{});
+    }
     // accumulators -> fp32 rows (LDS operations of one wave complete in order: no barrier)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -845,7 +909,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
         float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
                       hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
         const size_t o = (size_t)m * COUT + e_c0;
-        if constexpr (RESID) {
+        if constexpr (RESID && SPLIT) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[0][k][e] + (float)rv[1][k][e];  // hi + lo is exact in fp32
+        } else if constexpr (RESID) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)rv[i & 1][k][e];
         }
@@ -857,6 +924,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
           float* op = reinterpret_cast<float*>(outp) + o;
           *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if constexpr (SPLIT) {
+          f16x8 oh, ol;
+          split_pair8(v, oh, ol);
+          _Float16* op = reinterpret_cast<_Float16*>(outp) + (size_t)m * OPIX + e_c0;
+          *reinterpret_cast<f16x8*>(op) = oh;
+          *reinterpret_cast<f16x8*>(op + COUT) = ol;
         } else {
           frag ov;
 #pragma unroll
@@ -2064,6 +2137,71 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
   *reinterpret_cast<frag*>(out + (((size_t)b * HO + oh) * WO + ow) * C + c8 * 8) = o;
 }
 
+// fp16x3 mode: the same max-pool over the fp32 stem map (exact f32 MFMA), written as (hi, lo) fp16 pairs
+// [n,56,56, hi: 64 | lo: 64]
+template <typename TO>  // (a template only so that the header can be included from several translation units)
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const float* __restrict__ in, TO* __restrict__ out,
+                                                                 int n) {
+  static_assert(std::is_same<TO, _Float16>::value, "pairs are fp16");
+  constexpr int HI = 112, WI = 112, HO = 56, WO = 56, C = 64;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * HO * WO * (C / 8);
+  if (gid >= total) return;
+  const int c8 = (int)(gid % (C / 8));
+  long long p = gid / (C / 8);
+  const int ow = (int)(p % WO);
+  p /= WO;
+  const int oh = (int)(p % HO);
+  const int b = (int)(p / HO);
+  float best[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int ih = oh * 2 - 1 + dy;
+    if ((unsigned)ih >= (unsigned)HI) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iw = ow * 2 - 1 + dx;
+      if ((unsigned)iw >= (unsigned)WI) continue;
+      const float* src = in + (((size_t)b * HI + ih) * WI + iw) * C + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v0[e]), best[4 + e] = fmaxf(best[4 + e], v1[e]);
+    }
+  }
+  f16x8 oh8, ol8;
+  split_pair8(best, oh8, ol8);
+  _Float16* dst = out + (((size_t)b * HO + oh) * WO + ow) * (2 * C) + c8 * 8;
+  *reinterpret_cast<f16x8*>(dst) = oh8;
+  *reinterpret_cast<f16x8*>(dst + C) = ol8;
+}
+
+// fp16x3 mode, uint8 input: raw HWC patches -> the zero-padded fp32 NHWC4 tensor [n,230,232,4] through the fp32
+// ToTensor / Normalize table (exactly the reference's (v/255 - mean)/std per byte value, src/main.py:815-816)
+template <typename TO>
+__global__ __launch_bounds__(256) void u8_to_nhwc4_f32_kernel(const unsigned char* __restrict__ x,
+                                                              const float* __restrict__ lut, TO* __restrict__ out,
+                                                              int n) {
+  static_assert(std::is_same<TO, float>::value, "fp32 stem input");
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * kPadH * kPadW;
+  if (gid >= total) return;
+  const int px = (int)(gid % kPadW);
+  const long long t = gid / kPadW;
+  const int py = (int)(t % kPadH);
+  const int b = (int)(t / kPadH);
+  const int y = py - 3, xx = px - 3;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if ((unsigned)y < (unsigned)kPatch && (unsigned)xx < (unsigned)kPatch) {
+    const unsigned char* src = x + (((size_t)b * kPatch + y) * kPatch + xx) * 3;
+    v[0] = lut[src[0]];
+    v[1] = lut[256 + src[1]];
+    v[2] = lut[512 + src[2]];
+  }
+  *reinterpret_cast<f32x4*>(out + (size_t)gid * 4) = v;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device)
 constexpr int kMaxDevices = 64;
 static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
@@ -2103,7 +2241,7 @@ template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = 
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, bool RELU, bool RESID,
-          bool OUTF32, bool STEM = false>
+          bool OUTF32, bool STEM = false, bool SPLIT = false>
 static int launch_conv(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s,
                        const char* zero_page = nullptr) {
   constexpr int PAD = STEM ? 0 : KS / 2;
@@ -2116,7 +2254,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     dim3 grid((M + 127) / 128, COUT / BN);
     hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
                        grid, dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M);
-  } else if constexpr (HIPAC_USE_C64 && KS == 3 && STRIDE == 1 && CIN == 64 && COUT == 64 && HI == 56 && RELU && !OUTF32) {
+  } else if constexpr (HIPAC_USE_C64 && !SPLIT && KS == 3 && STRIDE == 1 && CIN == 64 && COUT == 64 && HI == 56 && RELU && !OUTF32) {
     const int n_tiles = n * 49;
     const int n_units = (n_tiles + 1) / 2;
     const int grid = n_units < 512 ? n_units : 512;  // persistent, 2 workgroups per CU
@@ -2132,7 +2270,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;  // deepest ring that keeps 2 workgroups/CU
     constexpr int STG = 4 * 32 * (BN / 2 * 4 + 16);  // epilogue staging, aliases the ring
     constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
-    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32>;
+    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT>;
     static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
     if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
@@ -2146,7 +2284,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
     constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
     constexpr int LDS = NSTAGE * (BM + BN) * 128;
-    auto kern = conv_glds_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BM, BN, NSTAGE, RELU, RESID, OUTF32>;
+    auto kern = conv_glds_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BM, BN, NSTAGE, RELU, RESID, OUTF32, false, SPLIT>;
     static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
     if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
@@ -2170,10 +2308,10 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
 
 // 3x3 / stride 2 conv (+BN+ReLU) of a down-sampling BasicBlock with its 1x1 / stride 2 projection
 // shortcut (+BN) riding along (conv_glds_kernel<..., PROJ = true>): x -> (out, out_p)
-template <typename T, int CIN, int COUT, int HI>
+template <typename T, int CIN, int COUT, int HI, bool SPLIT = false>
 static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* out, void* out_p, int n, hipStream_t s,
                        const char* zero_page) {
-  if constexpr (HIPAC_USE_S2C64 && CIN == 64 && COUT == 128 && HI == 56) {
+  if constexpr (HIPAC_USE_S2C64 && !SPLIT && CIN == 64 && COUT == 128 && HI == 56) {
     const int n_tiles = n * 28;
     const int grid = n_tiles < 512 ? n_tiles : 512;  // persistent, 2 workgroups per CU
     hipLaunchKernelGGL((conv3x3s2_c64_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias,
@@ -2186,7 +2324,7 @@ static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* ou
   constexpr int LDS = NSTAGE * (BM + BN) * 128;
   constexpr int HO = HI / 2;
   const int M = n * HO * HO;
-  auto kern = conv_glds_kernel<T, CIN, COUT, HI, HI, 3, 2, BM, BN, NSTAGE, true, false, false, true>;
+  auto kern = conv_glds_kernel<T, CIN, COUT, HI, HI, 3, 2, BM, BN, NSTAGE, true, false, false, true, SPLIT>;
   static bool attr_done[kMaxDevices] = {};
   if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
   const int n_mtiles = (M + BM - 1) / BM;
@@ -2219,14 +2357,14 @@ struct OpRange {
 
 // One ResNet stage = two BasicBlocks.  CI/HI: input channels / spatial size,
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
-template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST>
+template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false>
 static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
                      hipStream_t s, OpRange& ops, bool fuse_blocks = false) {
   constexpr int HO = HI / STRIDE;
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
-  if constexpr (CI == 64 && CO == 64 && HI == 56 && STRIDE == 1 && sizeof(T) == 2) {
+  if constexpr (CI == 64 && CO == 64 && HI == 56 && STRIDE == 1 && sizeof(T) == 2 && !SPLIT) {
     if (fuse_blocks) {
       // layer1: each BasicBlock is one launch (conv1 -> conv2 + shortcut on chip); the conv2 op slots stay empty
       const int per_xcd = 4 * ((n + 7) / 8);                   // strips on the busiest XCD
@@ -2252,31 +2390,43 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
     // one launch: conv1 and the projection shortcut (the op slot of the projection stays empty).
     // Not for layer4: its second accumulator set pushes the kernel past 256 registers, i.e. to
     // one workgroup per CU (measured 349 ns/img fused vs 132 + 37 separate).
-    if (ops.take()) HIPAC_TRY((launch_down<T, CI, CO, HI>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
+    if (ops.take()) HIPAC_TRY((launch_down<T, CI, CO, HI, SPLIT>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
     (void)ops.take();
     idt = ds;
   } else {
-    if (ops.take()) HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false>(x, bw[0], nullptr, tmp, n, s, z)));
+    if (ops.take())
+      HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false, false, SPLIT>(x, bw[0], nullptr, tmp, n, s, z)));
     if constexpr (STRIDE != 1 || CI != CO) {
       if (ops.take())
-        HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
+        HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false, false, SPLIT>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
       idt = ds;
     }
   }
-  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false>(tmp, bw[1], idt, o0, n, s, z)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false, false, SPLIT>(tmp, bw[1], idt, o0, n, s, z)));
   // block 1
-  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false>(o0, bw1[0], nullptr, tmp, n, s, z)));
-  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST>(tmp, bw1[1], o0, o1, n, s, z)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false, false, SPLIT>(o0, bw1[0], nullptr, tmp, n, s, z)));
+  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST, false, SPLIT>(tmp, bw1[1], o0, o1, n, s, z)));
   return 0;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                      hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
   const int ne = n_early, nl = n_late;
   bool fused_done = false;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (SPLIT) {
+    // fp16x3: the stem runs on the exact f32 MFMA (fp32 NHWC4 input, fp32 stem map), the pool writes (hi, lo) pairs
+    if (ops.take())
+      HIPAC_TRY((launch_conv<float, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
+    if (ops.take()) {
+      const long long total = (long long)ne * 56 * 56 * 8;
+      hipLaunchKernelGGL((maxpool3x3s2_split_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                         (const float*)(ws + p.stem), (_Float16*)(ws + p.pool), ne);
+      HIPAC_TRY((int)hipGetLastError());
+    }
+    fused_done = true;
+  } else if constexpr (sizeof(T) == 2) {
     if (p.fuse_stem) {
     // op 0 = fused stem + max-pool (the 112x112 stem map is never materialised), op 1 = nothing
     if (ops.take()) {
@@ -2302,6 +2452,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       fused_done = true;
     }
   }
+  if constexpr (!SPLIT)
   if (!fused_done) {
   if (ops.take())
     HIPAC_TRY((launch_conv<T, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
@@ -2313,12 +2464,12 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
   }
     }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
-  char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * sizeof(T);
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
-                                                p.l1_fused != 0)));
-  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
-  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops)));
+  char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * p.esz;
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false, SPLIT>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
+                                                       p.l1_fused != 0)));
+  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
+  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops)));
   return 0;
 }
 

@@ -38,7 +38,8 @@ static inline uint16_t f32_to_f16_bits(float f) {
 static inline uint16_t to_bits(float f, int precision) {
   return precision == HIPAC_PREC_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
 }
-static inline int elem_size(int precision) { return precision == HIPAC_PREC_FP32 ? 4 : 2; }
+static inline int elem_size(int precision) { return precision == HIPAC_PREC_FP32 || precision == HIPAC_PREC_FP16X3 ? 4 : 2; }
+static inline bool wide_mode(int precision) { return precision == HIPAC_PREC_FP32 || precision == HIPAC_PREC_FP16X3; }
 
 static int env_int(const char* name, int dflt, int lo, int hi) {
   if (const char* e = getenv(name)) {
@@ -57,10 +58,10 @@ Plan make_plan(int batch, int precision) {
   // (tuning knobs; a whole run must use one setting)
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
   const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
-  p.fuse_stem = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
+  p.fuse_stem = wide_mode(precision) ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
-  p.l1_fused = precision == HIPAC_PREC_FP32 ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
+  p.l1_fused = wide_mode(precision) ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -126,7 +127,7 @@ int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStr
     hipLaunchKernelGGL((nchw_to_nhwc4_kernel<__bf16>), dim3(grid), dim3(256), 0, s, x, (__bf16*)out, n);
   else if (precision == HIPAC_PREC_FP16)
     hipLaunchKernelGGL((nchw_to_nhwc4_kernel<_Float16>), dim3(grid), dim3(256), 0, s, x, (_Float16*)out, n);
-  else
+  else  // fp32 and fp16x3: the stem of both runs on fp32 input
     hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(grid), dim3(256), 0, s, x, (float*)out, n);
   return (int)hipGetLastError();
 }
@@ -202,11 +203,29 @@ __global__ __launch_bounds__(256) void tap_export_kernel(const T* __restrict__ s
   dst[(((size_t)b * C + c) * H + h) * W + w] = (float)src[gid];
 }
 
+// fp16x3: NHWC pairs [pixel][hi: C | lo: C] -> NCHW float32 (hi + lo is exact in fp32)
+__global__ __launch_bounds__(256) void tap_export_split_kernel(const _Float16* __restrict__ src, float* __restrict__ dst,
+                                                               int n, int C, int H, int W) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * C * H * W;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  long long t = gid / C;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const int b = (int)(t / H);
+  const _Float16* px = src + (gid / C) * (2 * C);
+  dst[(((size_t)b * C + c) * H + h) * W + w] = (float)px[c] + (float)px[C + c];
+}
+
 int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, int H, int W, float* dst,
                       hipStream_t s) {
   const long long total = (long long)n * C * H * W;
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (is_f32 || precision == HIPAC_PREC_FP32)
+  if (!is_f32 && precision == HIPAC_PREC_FP16X3)
+    hipLaunchKernelGGL(tap_export_split_kernel, dim3(grid), dim3(256), 0, s, (const _Float16*)src, dst, n, C, H, W);
+  else if (is_f32 || precision == HIPAC_PREC_FP32)
     hipLaunchKernelGGL((tap_export_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, dst, n, C, H, W);
   else if (precision == HIPAC_PREC_BF16)
     hipLaunchKernelGGL((tap_export_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, dst, n, C, H,
@@ -248,6 +267,38 @@ static int pack_conv(const hipac_convbn_t& c, int cout, int cin, int ks, float e
         }
   }
   int rc = f32 ? upload(w32.data(), w32.size() * 4, &out->w) : upload(w.data(), w.size() * 2, &out->w);
+  if (rc) return rc;
+  return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
+}
+
+// fp16x3: BN folded as in pack_conv, every weight split into hi = rn16(v), lo = rn16(v - hi); K order per tap =
+// 64-channel triples (hi_c | lo_c | hi_c) matching the activation chunks (hi_c, hi_c, lo_c) of the kernels' K loop
+// (conv_igemm.h, conv_glds_kernel's SPLIT note).
+static int pack_conv_split(const hipac_convbn_t& c, int cout, int cin, int ks, float eps, ConvW* out) {
+  HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
+                "pack: null tensor pointer (cout=%d cin=%d ks=%d)", cout, cin, ks);
+  HIPAC_REQUIRE(cin % 64 == 0, HIPAC_EINVAL, "pack: split layout needs cin %% 64 == 0 (%d)", cin);
+  const int K = ks * ks * 3 * cin;
+  std::vector<uint16_t> w((size_t)cout * K, 0);
+  std::vector<float> bias(cout);
+  for (int o = 0; o < cout; ++o) {
+    const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
+    bias[o] = (float)((double)c.bn_beta[o] - (double)c.bn_mean[o] * scale);
+    for (int i = 0; i < cin; ++i)
+      for (int kh = 0; kh < ks; ++kh)
+        for (int kw = 0; kw < ks; ++kw) {
+          const float v = (float)((double)c.conv_w[(((size_t)o * cin + i) * ks + kh) * ks + kw] * scale);
+          const uint16_t hb = f32_to_f16_bits(v);
+          _Float16 hh;
+          memcpy(&hh, &hb, 2);
+          const uint16_t lb = f32_to_f16_bits(v - (float)hh);
+          uint16_t* row = &w[(size_t)o * K + ((size_t)kh * ks + kw) * 3 * cin + (size_t)(i / 64) * 192 + (i % 64)];
+          row[0] = hb;
+          row[64] = lb;
+          row[128] = hb;
+        }
+  }
+  int rc = upload(w.data(), w.size() * 2, &out->w);
   if (rc) return rc;
   return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
 }
@@ -368,13 +419,15 @@ void hipac_weights_free(hipac_weights_t* w) {
   if (w->net.fc_b) (void)hipFree(w->net.fc_b);
   if (w->net.zero_page) (void)hipFree(w->net.zero_page);
   if (w->net.lut_t) (void)hipFree(w->net.lut_t);
+  if (w->net.lut_f32) (void)hipFree(w->net.lut_f32);
   if (w->lane_stream) (void)hipStreamDestroy(w->lane_stream);
   delete w;
 }
 
 int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hipac_weights_t** out) {
   HIPAC_REQUIRE(params && out, HIPAC_EINVAL, "pack: null argument");
-  HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16 || precision == HIPAC_PREC_FP32,
+  HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16 || precision == HIPAC_PREC_FP32 ||
+                    precision == HIPAC_PREC_FP16X3,
                 HIPAC_EINVAL, "pack: unknown precision %d", precision);
   HIPAC_REQUIRE(params->num_classes >= 0 && params->num_classes <= 16, HIPAC_EINVAL,
                 "pack: num_classes %d out of range", params->num_classes);
@@ -386,10 +439,20 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   w->net.precision = precision;
   w->net.num_classes = params->num_classes;
   const float eps = params->bn_eps;
-  int rc = pack_conv(params->stem, 64, 3, 7, eps, precision, true, &w->net.stem);
-  if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
+  const bool split = precision == HIPAC_PREC_FP16X3;
+  // fp16x3: the stem runs on the exact f32 MFMA (fp32 weights); every other conv on split pairs
+  int rc = pack_conv(params->stem, 64, 3, 7, eps, split ? HIPAC_PREC_FP32 : precision, true, &w->net.stem);
+  if (!rc && !wide_mode(precision)) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
   const int ch[4] = {64, 128, 256, 512};
-  for (int s = 0; s < 4 && !rc; ++s) {
+  for (int s = 0; s < 4 && !rc && split; ++s) {
+    const int cin = s == 0 ? 64 : ch[s - 1];
+    rc = pack_conv_split(params->block[2 * s][0], ch[s], cin, 3, eps, &w->net.block[2 * s][0]);
+    if (!rc) rc = pack_conv_split(params->block[2 * s][1], ch[s], ch[s], 3, eps, &w->net.block[2 * s][1]);
+    if (!rc) rc = pack_conv_split(params->block[2 * s + 1][0], ch[s], ch[s], 3, eps, &w->net.block[2 * s + 1][0]);
+    if (!rc) rc = pack_conv_split(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, &w->net.block[2 * s + 1][1]);
+    if (!rc && s > 0) rc = pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
+  }
+  for (int s = 0; s < 4 && !rc && !split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
     rc = pack_conv(params->block[2 * s][0], ch[s], cin, 3, eps, precision, false, &w->net.block[2 * s][0]);
     if (!rc) rc = pack_conv(params->block[2 * s][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s][1]);
@@ -406,13 +469,16 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     // reference src/main.py:815-816), then rounded to the network's storage type
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     std::vector<uint16_t> lut(3 * 256);
+    std::vector<float> lutf(3 * 256);
     for (int c = 0; c < 3; ++c)
       for (int v = 0; v < 256; ++v) {
         const float t = (float)v / 255.0f;
         const float d = t - mean[c];
-        lut[c * 256 + v] = to_bits(d / stdv[c], precision == HIPAC_PREC_FP32 ? HIPAC_PREC_BF16 : precision);
+        lutf[c * 256 + v] = d / stdv[c];
+        lut[c * 256 + v] = to_bits(d / stdv[c], wide_mode(precision) ? HIPAC_PREC_BF16 : precision);
       }
     rc = upload(lut.data(), lut.size() * 2, (void**)&w->net.lut_t);
+    if (!rc) rc = upload(lutf.data(), lutf.size() * 4, (void**)&w->net.lut_f32);
   }
   if (!rc && params->num_classes > 0) {
     HIPAC_REQUIRE(params->fc_b != nullptr, HIPAC_EINVAL, "pack: fc_b is null");
@@ -457,13 +523,15 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   Plan p = L.p;
   HIPAC_REQUIRE(workspace_bytes >= L.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
                 workspace_bytes, L.total);
-  HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem, HIPAC_EUNSUPPORTED,
-                "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0)");
-  p.u8_input = in_layout == HIPAC_IN_U8_HWC;
+  const bool split = w->net.precision == HIPAC_PREC_FP16X3;
+  HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem || split, HIPAC_EUNSUPPORTED,
+                "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0) or fp16x3");
+  p.u8_input = in_layout == HIPAC_IN_U8_HWC && !split;
   const Net& net = w->net;
   const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * p.esz;
   auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
-               : net.precision == HIPAC_PREC_FP16 ? run_trunk_f16 : run_trunk_f32;
+               : net.precision == HIPAC_PREC_FP16 ? run_trunk_f16
+               : split ? run_trunk_f16x3 : run_trunk_f32;
   // images [i0, i0 + n) on stream s with the lane's own workspace
   auto run_lane = [&](char* ws, int i0, int n, hipStream_t s) -> int {
     for (int g0 = i0; g0 < i0 + n; g0 += p.gc) {
@@ -474,6 +542,10 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
         if (in_layout == HIPAC_IN_NCHW_F32) {
           int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
                                         net.precision, s);
+          HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
+        } else if (in_layout == HIPAC_IN_U8_HWC && split) {
+          int rc = launch_u8_to_nhwc4_f32((const unsigned char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3, net.lut_f32,
+                                          (float*)(ws + p.xin), bn, s);
           HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
         } else if (in_layout == HIPAC_IN_U8_HWC) {
           xin = (const char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3;  // raw patches, normalise fused in the stem
@@ -533,12 +605,15 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
   HIPAC_REQUIRE(first_op > 0 || x != nullptr || in_layout == HIPAC_IN_NCHW_F32, HIPAC_EINVAL,
                 "run_ops: op 0 needs the input batch");
   char* ws = (char*)workspace;
+  const bool split = w->net.precision == HIPAC_PREC_FP16X3;
   auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
-               : w->net.precision == HIPAC_PREC_FP16 ? run_trunk_f16 : run_trunk_f32;
+               : w->net.precision == HIPAC_PREC_FP16 ? run_trunk_f16
+               : split ? run_trunk_f16x3 : run_trunk_f32;
   // early ops act on the first sub-batch, late ops on the whole group; an NCHW input was
   // converted into the workspace by the preceding forward
   p.u8_input = in_layout == HIPAC_IN_U8_HWC && p.fuse_stem;
-  const void* xin = in_layout == HIPAC_IN_NCHW_F32 ? (const void*)(ws + p.xin) : x;
+  // (fp16x3 with uint8 input: converted into the workspace by the preceding forward, like NCHW)
+  const void* xin = in_layout == HIPAC_IN_NCHW_F32 || (split && in_layout == HIPAC_IN_U8_HWC) ? (const void*)(ws + p.xin) : x;
   const int ne = batch < p.bc ? batch : p.bc;
   return trunk(w->net, p, ws, xin, ne, 0, batch, (hipStream_t)stream, first_op, last_op);
 }
@@ -556,6 +631,7 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
     HIPAC_REQUIRE(!p.fuse_stem, HIPAC_EUNSUPPORTED,
                   "tap 0 (stem) does not exist when the stem is fused with the max-pool; set HIPAC_FUSE_STEM=0");
     src = ws + p.stem, C = 64, H = 112;
+    is_f32 = w->net.precision == HIPAC_PREC_FP16X3;  // its stem map is fp32
   } else if (tap == 1) {
     src = ws + p.pool, C = 64, H = 56;
   } else {

@@ -10,14 +10,15 @@ u8 = synth.synth_patches_u8(24, seed=31)
 x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
 ref_f, ref_l = R.resnet18_forward(x, sd)
 rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
-for prec in ("fp32", "fp16", "bf16"):
+for prec in ("fp32", "fp16x3", "fp16", "bf16"):
     net = capi.PackedResNet18(sd, precision=prec)
     f, l, lab = net.forward(u8.cuda(), want_logits=True, want_labels=True)
     elem = float(((f.cpu() - ref_f).abs() / ref_f.abs().clamp_min(1e-3)).max())
     print(f"{prec}: features norm-rel {rel(f, ref_f):.2e} elementwise-rel {elem:.2e}  logits norm-rel {rel(l, ref_l):.2e} "
           f"abs {float((l.cpu()-ref_l).abs().max()):.2e}  labels equal {int((lab.cpu()==ref_l.argmax(1)).sum())}/24")
-net = capi.PackedResNet18(sd, precision="fp32")
-xb = torch.randn(2048, 3, 224, 224, device="cuda")
-net.forward(xb); torch.cuda.synchronize()
-t0 = time.time(); net.forward(xb); torch.cuda.synchronize(); dt = time.time() - t0
-print(f"fp32 parity mode: {2048/dt:.0f} patches/s ({2048/dt*3.627e9/1e12:.1f} TFLOP/s, f32 MFMA peak 157)")
+xb = torch.randint(0, 256, (4096, 224, 224, 3), dtype=torch.uint8, device="cuda")
+for prec in ("fp32", "fp16x3"):
+    net = capi.PackedResNet18(sd, precision=prec)
+    net.forward(xb); torch.cuda.synchronize()
+    t0 = time.time(); net.forward(xb); torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"{prec}: {4096/dt:.0f} patches/s ({4096/dt*3.627e9/1e12:.1f} TFLOP/s of network arithmetic)")
