@@ -362,6 +362,24 @@ def run_resnet(args, rank, world, dev):
             rec["alt_precision"] = {"dtype": alt_name, "value": B * args.steps / (time.perf_counter() - t0),
                                     "unit": "patches/s"}
             nets[alt_name] = alt
+        # the parity mode: fp16 (hi, lo) pairs, three MFMA products per term -- the same workload, the same number of steps
+        netx3 = capi.PackedResNet18(sd, precision="fp16x3")
+        for i in range(max(1, min(2, args.warmup))):
+            netx3.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            netx3.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
+        torch.cuda.synchronize()
+        vx3 = B * args.steps / (time.perf_counter() - t0)
+        rec["parity_mode"] = {"dtype": "fp16x3", "value": vx3, "unit": "patches/s", "patches": B * args.steps,
+                              "tflops_network_arithmetic": vx3 * FLOP_PER_PATCH / 1e12,
+                              "tflops_mfma_issued": 3 * vx3 * FLOP_PER_PATCH / 1e12,
+                              "frac_of_f16_mfma_peak": 3 * vx3 * FLOP_PER_PATCH / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                              "note": "every product = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2 products in the stem: "
+                                      "bytes are exact); meets_1e-3 is measured in `parity`"}
+        nets["fp16x3"] = netx3
+        # the debugging reference: fp32 storage, exact f32 MFMA
         net32 = capi.PackedResNet18(sd, precision="fp32")
         n32 = min(B, 2048)
         net32.forward(data[0][:n32].contiguous(), want_feats=True, want_logits=True, want_labels=True)
@@ -370,8 +388,9 @@ def run_resnet(args, rank, world, dev):
         net32.forward(data[0][:n32].contiguous(), want_feats=True, want_logits=True, want_labels=True)
         torch.cuda.synchronize()
         v32 = n32 / (time.perf_counter() - t0)
-        rec["parity_mode"] = {"dtype": "fp32", "value": v32, "unit": "patches/s", "patches": n32,
-                              "tflops": v32 * FLOP_PER_PATCH / 1e12, "frac_of_f32_mfma_peak": v32 * FLOP_PER_PATCH / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        rec["debug_reference_mode"] = {"dtype": "fp32", "value": v32, "unit": "patches/s", "patches": n32,
+                                       "tflops": v32 * FLOP_PER_PATCH / 1e12, "frac_of_f32_mfma_peak": v32 * FLOP_PER_PATCH / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        rec["parity_mode"]["vs_fp32_mode"] = vx3 / v32
         nets["fp32"] = net32
         rec["pcie_inclusive"] = pcie_inclusive(net, data[0], steps=min(4, args.steps))
         if not args.no_cpu_baseline:

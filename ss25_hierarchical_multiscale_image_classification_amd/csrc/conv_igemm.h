@@ -1245,10 +1245,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 // Fused stem, uint8 input, second form ("strip" kernel, stem_pool_strip2_kernel below): the same 7x7/2 conv +
 // BN + ReLU + 3x3/2 max-pool on raw uint8 HWC patches, restructured around the MFMA loop:
 //   * ToTensor / Normalize are folded into the weights and the bias at pack time: the kernel
-//     multiplies the byte value v itself (exact in bf16 and fp16) by w'' = w / (255 std_c) and the bias
-//     carries -sum(w'' mu''_c), mu''_c = 255 mean_c; pixels outside the image take the value mu''_c
-//     (rounded to T), i.e. the normalised 0 the reference pads with.  No table, no per-pixel
-//     rounding of the input.
+//     multiplies the centred byte value v - 128 (an exact integer in bf16 and fp16) by w'' = w / (255 std_c)
+//     and a bias table carries sum(w'' (128 - mu''_c)), mu''_c = 255 mean_c, over the taps inside the image and
+//     128 sum(w'') over the taps outside (bytes there arrive as 0, i.e. -128, where the reference pads with the
+//     normalised 0).  No per-pixel rounding of the input.
 //   * K is packed as (channel plane c, row pair rp, column quad cq) = 3 x 4 x 2 fragments of 8
 //     = 192 (147 real), 12 k16 steps instead of 14.  In LDS a plane holds, per column, the two rows
 //     of a row pair in one dword, so the fragment of stem column sx (input columns 2sx-3+4cq ..+3,
@@ -1311,13 +1311,20 @@ constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 #ifndef HIPAC_STRIP_PRIO
 #define HIPAC_STRIP_PRIO 2  // 0: no s_setprio, 1: around the MFMA loop, 2: on the vector half
 #endif
-template <typename T>
+// SPLIT (fp16x3 mode): the byte values are exact in fp16, so only the weights are pairs: `wgt` holds the hi halves
+// [64][192] followed by the lo halves [64][192]; hi stays in registers, lo is fetched from LDS per channel plane, and
+// every fragment feeds two MFMAs per (row, row pair).  The pooling stays in fp32 (v_max3 in y, two DPP shifts in x,
+// ReLU) and the pooled rows leave as (hi, lo) pairs [pixel][hi: 64 | lo: 64], hi then lo through the same staging.
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned char* __restrict__ x,
                                                                   const T* __restrict__ wgt,
                                                                   const float* __restrict__ btab, T* __restrict__ out,
                                                                   int n_strips, int in_bytes) {
   using E = Elem<T>;
   using frag = typename E::frag;
+  static_assert(!SPLIT || std::is_same<T, _Float16>::value, "split pairs are fp16");
+  constexpr int OPIX = SPLIT ? 128 : 64;              // elements per output pixel
+  constexpr int WLO_BYTES = SPLIT ? 2 * 12 * 1024 : 0;  // low weight halves in fragment order: [channel half][k16 step][lane] x 16 B
   constexpr int NRP = 11, PXW = 128;
   constexpr int PLANE = NRP * PXW * 4;
   constexpr int PATCH_BYTES = 3 * PLANE;              // 16 896
@@ -1326,7 +1333,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
   constexpr int TEAM_BYTES = PATCH_BYTES + RAW_BYTES;
   constexpr int CARRY_BYTES = 512 * 64;               // per lane 16 floats: the raw last stem row of the previous step
   constexpr int STG_BYTES = 4 * 14 * 64;              // per wave: 4 pooled rows x 14 pixels x 32 channels of T
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 4096];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 4096 + WLO_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1342,10 +1349,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
   unsigned char* const Sl = smem + 2 * TEAM_BYTES + CARRY_BYTES + wave * STG_BYTES;
   // Initial accumulators, in LDS (a global load inside the step loop would wait -- vmcnt retires in order -- for the
   // rows just requested): table [row class][column class][64 channels] = folded bias + the border correction.
-  // The kernel feeds 0 for every byte outside the image (rows and whole dwords of columns are zero-filled by the
-  // DMA's range check: nothing to mask in the conversion), while the reference pads with the normalised 0, i.e. the
-  // byte value mu_c = 255 mean_c: the difference, sum over the taps outside of w mu_c, depends only on which taps
-  // are outside -- stem row 0 / 1 / 111 / other x stem column 0 / 1 / 111 / other -- and is part of the table.
+  // Every byte outside the image arrives as 0 (rows and whole dwords of columns are zero-filled by the DMA's range
+  // check: nothing to mask in the conversion) and is fed as 0 - 128, while the reference pads with the normalised 0,
+  // i.e. the byte value mu_c = 255 mean_c: the difference depends only on which taps are outside -- stem row
+  // 0 / 1 / 111 / other x stem column 0 / 1 / 111 / other -- and is part of the table.
   float* const Bl = reinterpret_cast<float*>(smem + 2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES);
   for (int i = tid; i < 16 * 64; i += 512) Bl[i] = btab[i];  // visible after the first phase barrier (first read: H1(0))
   int s_off[4];  // element offset of chunk lane + 64 m from the step's first pixel
@@ -1353,12 +1360,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
   for (int m = 0; m < 4; ++m) {
     const int c = lane + 64 * m, pix = c >> 2;
     const int q = (pix * 147) >> 11, k = pix - 14 * q;
-    s_off[m] = (q * 56 + k) * 64 + (c & 3) * 8;
+    // SPLIT: the staging holds two pooled rows at a time, hi rows then lo rows: staged row q = (half, row & 1)
+    s_off[m] = SPLIT ? ((q & 1) * 56 + k) * 128 + (q >> 1) * 64 + (c & 3) * 8 : (q * 56 + k) * 64 + (c & 3) * 8;
   }
 
+  const float unscale = SPLIT ? btab[16 * 64] : 1.f;  // 2^-S of the split weights' scale (pack_stem_u8)
   frag wreg[12];
+  unsigned char* const Wl = smem + 2 * TEAM_BYTES + CARRY_BYTES + 8 * STG_BYTES + 4096 + jt * (12 * 1024) + lane * 16;
   {
     const char* wb = reinterpret_cast<const char*>(wgt) + (size_t)(jt * 32 + r) * (192 * 2) + 16 * h;
+    if constexpr (SPLIT) {
+      if (team == 0 && st == 0) {  // one wave per channel half parks the lo fragments (visible after the first phase barrier)
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+          *reinterpret_cast<frag*>(Wl + s * 1024) = *reinterpret_cast<const frag*>(wb + 64 * 192 * 2 + s * 32);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 12; ++s) wreg[s] = *reinterpret_cast<const frag*>(wb + s * 32);
 #pragma unroll
@@ -1413,7 +1430,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 #pragma unroll
       for (int px = 0; px < 8; ++px) {
         const int w = 1 + 3 * px + c;  // byte inside the dword run
-        o[px] = PackPair<T>::pack((float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu), (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu));
+        // v - 128: still an exact integer in bf16 / fp16, and the fp32 accumulation no longer carries the DC term
+        // 128 sum(w) (bytes outside the image arrive as 0 -> -128: the bias table accounts for them)
+        o[px] = PackPair<T>::pack((float)((da[w >> 2] >> (8 * (w & 3))) & 0xffu) - 128.f,
+                                  (float)((db[w >> 2] >> (8 * (w & 3))) & 0xffu) - 128.f);
       }
       *reinterpret_cast<u32x4*>(cdst + c * PLANE) = u32x4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<u32x4*>(cdst + c * PLANE + 16) = u32x4{o[4], o[5], o[6], o[7]};
@@ -1464,9 +1484,18 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 #ifdef HIPAC_ABL_STRIP_STORE_LOCAL
           T* const dst0 = out + (size_t)blockIdx.x * 16384 + jt * 32 + (b & 0);
 #else
-          T* const dst0 = out + ((((size_t)b * 56 + 4 * ys) * 56 + 28 * side + 14 * st) * 64 + jt * 32);
+          T* const dst0 = out + ((((size_t)b * 56 + 4 * ys) * 56 + 28 * side + 14 * st) * OPIX + jt * 32);
 #endif
           typedef __attribute__((ext_vector_type(2))) short s16x2;
+          // SPLIT: rows go out two at a time (hi halves in staging rows 0, 1, lo halves in rows 2, 3)
+          auto flush_pair = [&](int g) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's staging writes
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (m < 3 || lane < 32)
+                *reinterpret_cast<u32x4*>(dst0 + g * (2 * 56 * 128) + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the rows are overwritten
+          };
           // one pooled row at a time: y max (fp32, v_max3), round to T, then the x max of lanes r, r+1, r+2 by two
           // DPP wave shifts and ReLU, both on the 16-bit patterns as SIGNED integers -- among non-negative
           // floats that is the float order, every negative float is below every non-negative one, and the
@@ -1474,6 +1503,32 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
           static_for<4>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             unsigned pk[8];
+            unsigned lk_prev = 0;
+            (void)lk_prev;
+            if constexpr (SPLIT) {
+              // fp32 all the way: y max, x max of lanes r, r+1, r+2 (two wave shifts), ReLU; then the (hi, lo) split
+#pragma unroll
+              for (int d = 0; d < 8; ++d) {
+                float pv[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                  const int e = 2 * d + t;
+                  const float top = q == 0 ? carry[e] : acc[q == 0 ? 0 : 2 * q - 1][e];
+                  const float a0 = col_m1 ? -3.0e38f : fmaxf(fmaxf(top, acc[2 * q][e]), acc[2 * q + 1][e]);
+                  const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x130, 0xf, 0xf, false));
+                  const float t1 = fmaxf(a0, a1);
+                  const float u2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x130, 0xf, 0xf, false));
+                  pv[t] = fmaxf(fmaxf(t1, u2), 0.f) * unscale;
+                }
+                const f16x2 h2 = __builtin_convertvector(f32x2{pv[0], pv[1]}, f16x2);
+                const f16x2 l2 = __builtin_convertvector(f32x2{pv[0] - (float)h2[0], pv[1] - (float)h2[1]}, f16x2);
+                pk[d] = __builtin_bit_cast(unsigned, h2);
+                if (writer && (d & 1))  // (d - 1, d) = one 8-byte item of channel quad d / 2
+                  *reinterpret_cast<u32x2*>(Sl + ((2 + (q & 1)) * 14 + (r >> 1)) * 64 + (d >> 1) * 16 + h * 8) =
+                      u32x2{lk_prev, __builtin_bit_cast(unsigned, l2)};
+                lk_prev = __builtin_bit_cast(unsigned, l2);
+              }
+            } else {
 #pragma unroll
             for (int cq = 0; cq < 4; ++cq) {
               float v[4];
@@ -1486,6 +1541,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
               pk[2 * cq] = PackPair<T>::pack_rn(v[0], v[1]);
               pk[2 * cq + 1] = PackPair<T>::pack_rn(v[2], v[3]);
             }
+            }
+            if constexpr (!SPLIT)
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
               const unsigned a0 = col_m1 ? 0x80008000u : pk[d];  // -0.0: below every value as int16, never wins
@@ -1498,12 +1555,16 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             if (writer) {
 #pragma unroll
               for (int cq = 0; cq < 4; ++cq)
-                *reinterpret_cast<u32x2*>(Sl + (q * 14 + (r >> 1)) * 64 + cq * 16 + h * 8) = u32x2{pk[2 * cq], pk[2 * cq + 1]};
+                *reinterpret_cast<u32x2*>(Sl + ((SPLIT ? (q & 1) : q) * 14 + (r >> 1)) * 64 + cq * 16 + h * 8) = u32x2{pk[2 * cq], pk[2 * cq + 1]};
             }
+            if constexpr (SPLIT && q == 1) flush_pair(0);
           });
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             *reinterpret_cast<f32x4*>(Cl + k * 8192) = f32x4{acc[7][4 * k], acc[7][4 * k + 1], acc[7][4 * k + 2], acc[7][4 * k + 3]};
+          if constexpr (SPLIT) {
+            flush_pair(1);
+          } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's staging writes (LDS operations of a wave complete in order)
 #ifdef HIPAC_ABL_STRIP_NO_STORE
           if (n_strips < 0)
@@ -1512,6 +1573,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
           for (int m = 0; m < 4; ++m)
             if (m < 3 || lane < 32)
               *reinterpret_cast<u32x4*>(dst0 + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
+          }
         }
         HALO_STAMP(z_te);
 #ifdef HIPAC_HALO_STAMPS
@@ -1523,7 +1585,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             issue_dma(tg, 0);  // prologue: nothing was requested yet
             wait_vmcnt<0>();
           } else {
-            wait_vmcnt<4>();  // this wave's raw rows of step n+1 (requested at the end of H2(n-1)) are older than its 4 stores
+            wait_vmcnt<SPLIT ? 8 : 4>();  // this wave's raw rows of step n+1 (requested at the end of H2(n-1)) are older than its 4 (8) stores
           }
           HALO_STAMP(z_tw);
 #ifdef HIPAC_ABL_STRIP_NO_CONVERT
@@ -1591,6 +1653,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             const u32x2 lo = *reinterpret_cast<const u32x2*>(pp), hi = *reinterpret_cast<const u32x2*>(pp + 8);
             ring3[f % 3] = __builtin_bit_cast(frag, u32x4{lo[0], lo[1], hi[0], hi[1]});
           };
+          frag wlo[SPLIT ? 4 : 1];  // SPLIT: the lo weight fragments of the current channel plane
+          auto rdw = [&](int c_) {
+            if constexpr (SPLIT) {
+#pragma unroll
+              for (int rp = 0; rp < 4; ++rp) wlo[rp] = *reinterpret_cast<const frag*>(Wl + (c_ * 4 + rp) * 1024);
+            }
+          };
+          rdw(0);
           rd(std::integral_constant<int, 0>{});
           rd(std::integral_constant<int, 1>{});
           static_for<33>([&](auto F) {
@@ -1603,6 +1673,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
                 else acc[i] = E::mfma(wreg[c * 4 + rp], ring3[f % 3], acc[i]);
               }
             });
+            if constexpr (SPLIT) {
+              static_for<4>([&](auto RP) {
+                constexpr int rp = decltype(RP)::value, i = j - rp;
+                if constexpr (i >= 0 && i < 8) acc[i] = E::mfma(wlo[rp], ring3[f % 3], acc[i]);
+              });
+              if constexpr (j == NRP - 1 && c < 2) rdw(c + 1);  // the next plane's lo fragments, one fragment ahead
+            }
             __builtin_amdgcn_sched_barrier(0);
           });
         }
@@ -2416,7 +2493,20 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
   const int ne = n_early, nl = n_late;
   bool fused_done = false;
   if constexpr (SPLIT) {
-    // fp16x3: the stem runs on the exact f32 MFMA (fp32 NHWC4 input, fp32 stem map), the pool writes (hi, lo) pairs
+    if (p.u8_input && p.stem_strip) {
+      // fp16x3, uint8 input: the strip kernel with split weights (bytes are exact in fp16); op 1 = nothing
+      if (ops.take()) {
+        const int n_strips = 2 * ne;
+        const int n_pairs = (n_strips + 1) / 2;
+        const int sgrid = n_pairs < 256 ? n_pairs : 256;
+        hipLaunchKernelGGL((stem_pool_strip2_kernel<T, true>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
+                           (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
+                           ne * kPatch * kPatch * 3);
+        HIPAC_TRY((int)hipGetLastError());
+      }
+      (void)ops.take();
+    } else {
+    // float input: the stem runs on the exact f32 MFMA (fp32 NHWC4 input, fp32 stem map), the pool writes (hi, lo) pairs
     if (ops.take())
       HIPAC_TRY((launch_conv<float, 4, 64, 224, 224, 7, 2, true, false, false, true>(xin, net.stem, nullptr, ws + p.stem, ne, s)));
     if (ops.take()) {
@@ -2424,6 +2514,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       hipLaunchKernelGGL((maxpool3x3s2_split_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                          (const float*)(ws + p.stem), (_Float16*)(ws + p.pool), ne);
       HIPAC_TRY((int)hipGetLastError());
+    }
     }
     fused_done = true;
   } else if constexpr (sizeof(T) == 2) {

@@ -304,10 +304,11 @@ static int pack_conv_split(const hipac_convbn_t& c, int cout, int cin, int ks, f
 }
 
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
-// pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the byte
-// value v itself (exact in bf16 and fp16) and 0 outside the image, so w'' = w * scale / (255 std_c) and the
-// bias takes - sum w'' mu''_c, mu''_c = 255 mean_c (the byte value of the normalised 0 the reference pads with),
-// over the taps INSIDE the image: one bias per (row class, column class) of the stem pixel, 16 x 64 floats.
+// pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the centred byte
+// value v - 128 (exact in bf16 and fp16; bytes outside the image arrive as 0, i.e. -128), so w'' = w * scale / (255 std_c)
+// and the bias takes sum w'' (128 - mu''_c), mu''_c = 255 mean_c (the byte value of the normalised 0 the reference
+// pads with), over the taps INSIDE the image and 128 sum w'' over the taps outside: one bias per (row class, column
+// class) of the stem pixel, 16 x 64 floats.
 // The fold uses the ROUNDED weights, so what is left of the weight rounding multiplies the centred value
 // v - mu'', as in the unfolded form.
 // K order: k = 16 s + 8 h + j, s = 4 c + rp, kh = 2 rp + (j & 1), kw = 4 h + (j >> 1); kh, kw = 7 are zero.
@@ -323,10 +324,28 @@ static float round_to(float v, int precision) {
   memcpy(&hh, &b, 2);
   return (float)hh;
 }
+// precision HIPAC_PREC_FP16X3: w = the hi halves [64][192] followed by the lo halves [64][192] (fp16 pairs)
 static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW* out) {
   const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
-  std::vector<uint16_t> w((size_t)64 * 192, 0);
-  std::vector<float> tab((size_t)16 * 64);
+  const bool split = precision == HIPAC_PREC_FP16X3;
+  std::vector<uint16_t> w((size_t)64 * 192 * (split ? 2 : 1), 0);
+  std::vector<float> tab((size_t)16 * 64 + 1);  // + tab[1024]: the factor that undoes the split weights' power-of-two scale
+  // fp16x3: the folded weights are ~1e-3 (w / (255 std)), whose lo halves would be fp16 subnormals (2^-24 quantum = only
+  // 2^-15 of the weight): everything is scaled by 2^S (exact) so that the largest weight sits near 2^13, and the kernel
+  // multiplies the pooled result by 2^-S
+  double wscale = 1.0;
+  if (split) {
+    double wmax = 0.0;
+    for (int o = 0; o < 64; ++o) {
+      const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
+      for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < 49; ++k) wmax = fmax(wmax, fabs((double)c.conv_w[((size_t)o * 3 + ch) * 49 + k] * scale / (255.0 * stdv[ch])));
+    }
+    int S = wmax > 0.0 ? (int)floor(log2(8192.0 / wmax)) : 0;
+    S = S < 0 ? 0 : (S > 24 ? 24 : S);
+    wscale = ldexp(1.0, S);
+  }
+  tab[16 * 64] = (float)(1.0 / wscale);
   double mu[3];
   for (int ch = 0; ch < 3; ++ch) mu[ch] = 255.0 * mean[ch];
   // taps of a stem pixel that fall outside the image, by class: 0 none, 1: row / column 0 (taps 0-2), 2: row / column 1
@@ -338,19 +357,28 @@ static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW
     for (int ch = 0; ch < 3; ++ch)
       for (int kh = 0; kh < 7; ++kh)
         for (int kw = 0; kw < 7; ++kw) {
-          const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale / (255.0 * stdv[ch]);
+          const double v = (double)c.conv_w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw] * scale / (255.0 * stdv[ch]) * wscale;
           const int s = 4 * ch + (kh >> 1), hq = kw >> 2, j = 2 * (kw & 3) + (kh & 1);
-          w[(size_t)o * 192 + 16 * s + 8 * hq + j] = to_bits((float)v, precision);
-          rw[ch][kh][kw] = (double)round_to((float)v, precision);
+          if (split) {
+            const float hi = round_to((float)v, HIPAC_PREC_FP16), lo = round_to((float)v - hi, HIPAC_PREC_FP16);
+            w[(size_t)o * 192 + 16 * s + 8 * hq + j] = to_bits(hi, HIPAC_PREC_FP16);
+            w[(size_t)(64 + o) * 192 + 16 * s + 8 * hq + j] = to_bits(lo, HIPAC_PREC_FP16);
+            rw[ch][kh][kw] = (double)hi + (double)lo;
+          } else {
+            w[(size_t)o * 192 + 16 * s + 8 * hq + j] = to_bits((float)v, precision);
+            rw[ch][kh][kw] = (double)round_to((float)v, precision);
+          }
         }
-    const double b0 = (double)c.bn_beta[o] - (double)c.bn_mean[o] * scale;
+    const double b0 = ((double)c.bn_beta[o] - (double)c.bn_mean[o] * scale) * wscale;
     for (int rc = 0; rc < 4; ++rc)
       for (int cc = 0; cc < 4; ++cc) {
-        double b = b0;  // bias - sum over the taps INSIDE the image of w mu (the kernel feeds 0 outside)
+        // the kernel feeds v - 128 inside the image and 0 - 128 outside; the reference's sum is w (v - mu) over the
+        // taps inside: bias + sum_inside w (128 - mu) + sum_outside 128 w
+        double b = b0;
         for (int ch = 0; ch < 3; ++ch)
           for (int kh = 0; kh < 7; ++kh)
             for (int kw = 0; kw < 7; ++kw)
-              if (!tap_out(rc, kh) && !tap_out(cc, kw)) b -= rw[ch][kh][kw] * mu[ch];
+              b += (!tap_out(rc, kh) && !tap_out(cc, kw)) ? rw[ch][kh][kw] * (128.0 - mu[ch]) : rw[ch][kh][kw] * 128.0;
         tab[((size_t)rc * 4 + cc) * 64 + o] = (float)b;
       }
   }
@@ -442,7 +470,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   const bool split = precision == HIPAC_PREC_FP16X3;
   // fp16x3: the stem runs on the exact f32 MFMA (fp32 weights); every other conv on split pairs
   int rc = pack_conv(params->stem, 64, 3, 7, eps, split ? HIPAC_PREC_FP32 : precision, true, &w->net.stem);
-  if (!rc && !wide_mode(precision)) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
+  if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc && split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
@@ -526,7 +554,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   const bool split = w->net.precision == HIPAC_PREC_FP16X3;
   HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem || split, HIPAC_EUNSUPPORTED,
                 "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0) or fp16x3");
-  p.u8_input = in_layout == HIPAC_IN_U8_HWC && !split;
+  p.u8_input = in_layout == HIPAC_IN_U8_HWC && (!split || p.stem_strip);  // fp16x3 without the strip kernel: converted to fp32 below
   const Net& net = w->net;
   const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * p.esz;
   auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
@@ -543,7 +571,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
           int rc = launch_nchw_to_nhwc4((const float*)x + (size_t)(g0 + b0) * 3 * kPatch * kPatch, ws + p.xin, bn,
                                         net.precision, s);
           HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
-        } else if (in_layout == HIPAC_IN_U8_HWC && split) {
+        } else if (in_layout == HIPAC_IN_U8_HWC && !p.u8_input) {
           int rc = launch_u8_to_nhwc4_f32((const unsigned char*)x + (size_t)(g0 + b0) * kPatch * kPatch * 3, net.lut_f32,
                                           (float*)(ws + p.xin), bn, s);
           HIPAC_REQUIRE(rc == 0, rc, "forward: input conversion launch failed (%d)", rc);
@@ -611,9 +639,10 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
                : split ? run_trunk_f16x3 : run_trunk_f32;
   // early ops act on the first sub-batch, late ops on the whole group; an NCHW input was
   // converted into the workspace by the preceding forward
-  p.u8_input = in_layout == HIPAC_IN_U8_HWC && p.fuse_stem;
-  // (fp16x3 with uint8 input: converted into the workspace by the preceding forward, like NCHW)
-  const void* xin = in_layout == HIPAC_IN_NCHW_F32 || (split && in_layout == HIPAC_IN_U8_HWC) ? (const void*)(ws + p.xin) : x;
+  p.u8_input = in_layout == HIPAC_IN_U8_HWC && (split ? p.stem_strip : p.fuse_stem);
+  // (fp16x3 with uint8 input and HIPAC_STEM_STRIP=0: converted into the workspace by the preceding forward, like NCHW)
+  const void* xin = in_layout == HIPAC_IN_NCHW_F32 || (split && in_layout == HIPAC_IN_U8_HWC && !p.u8_input)
+                        ? (const void*)(ws + p.xin) : x;
   const int ne = batch < p.bc ? batch : p.bc;
   return trunk(w->net, p, ws, xin, ne, 0, batch, (hipStream_t)stream, first_op, last_op);
 }

@@ -54,9 +54,11 @@ def _oracle_rows(levels_np, polys, sd, levels):
     return np.array(rows, np.int32), ref_f, ref_l
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 2e-5), ("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2.5e-2)])
 def test_score_slide_all_levels_matches_oracle(prec, tol):
-    """BASELINE configs[2] end to end, level 0 included (`--patch_level all`, src/main.py:1120-1122): a slide with
+    """(fp16x3 = the parity mode: north_star's 1e-3 on features AND logits, asserted here at 2e-5 (measured 1.5e-6 /
+    3.7e-6), labels identical.)
+    BASELINE configs[2] end to end, level 0 included (`--patch_level all`, src/main.py:1120-1122): a slide with
     ragged right / bottom edges (level-0 windows of 1792 px clipped at both borders, 132 of them on the stride-224
     grid), windows / order / labels identical to the oracle's extractor, features and logits within the
     precision's tolerance.  Level 0 is the BIG level of score_slide's schedule: its windows are decided and
@@ -78,6 +80,8 @@ def test_score_slide_all_levels_matches_oracle(prec, tol):
         torch.cuda.synchronize()
         assert np.array_equal(meta.cpu().numpy(), rows)  # same windows, same labels, reference order
         assert rel(feats, ref_f) <= tol and rel(logits, ref_l) <= tol, (prec, kw)
+        if prec == "fp16x3":
+            assert rel(feats, ref_f) <= 1e-3 and rel(logits, ref_l) <= 1e-3
         margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
         decided = margin > 2 * tol * ref_l.abs().max()
         assert torch.equal(preds.cpu()[decided], ref_l.argmax(1)[decided])
