@@ -28,8 +28,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -38,7 +36,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ss25_hierarchical_multiscale_image_classification_amd import capi, dist as hdist, synth  # noqa: E402
+from ss25_hierarchical_multiscale_image_classification_amd import capi, dist as hdist, launch as hlaunch, synth  # noqa: E402
 
 FLOP_PER_PATCH = 2 * 1_813_562_368  # convs + fc, BN folded
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
@@ -489,40 +487,19 @@ def run_simclr(args, rank, world, dev):
 # ---------------------------------------------------------------------------------------------------------
 
 def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    return hlaunch.free_port()
 
 
 def child_commands(argv, n: int, port: int, python: str = sys.executable, base_env=None):
     """(argv, env) of every rank's process: the same command line plus --_child, torchrun's environment
     variables, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
-    base_env = dict(os.environ if base_env is None else base_env)
-    cmds = []
-    for r in range(n):
-        env = dict(base_env)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL fails without it on this driver
-        cmds.append(([python, os.path.join(ROOT, "bench.py"), *[a for a in argv if a != "--_child"], "--_child"], env))
-    return cmds
+    return hlaunch.child_commands([os.path.join(ROOT, "bench.py")], argv, n, port, python=python, base_env=base_env)
 
 
-def launch_ranks(argv, n: int) -> int:
-    """Start one fresh process per rank BEFORE this process touches the GPU, relay rank 0's stdout, wait for
-    all; exit code = first non-zero child code."""
-    procs = []
-    for r, (cmd, env) in enumerate(child_commands(argv, n, _free_port())):
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    if bad:
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
-        return bad[0]
-    return 0
+def launch_ranks(argv, n: int, rank_timeout=None) -> int:
+    """Start one fresh process per rank BEFORE this process touches the GPU, relay rank 0's stdout; every child is
+    polled, and when one exits non-zero the others are terminated and its code is returned (launch.py)."""
+    return hlaunch.launch_ranks(child_commands(argv, n, _free_port()), rank_timeout=rank_timeout, name="bench.py")
 
 
 def build_parser():
@@ -543,6 +520,8 @@ def build_parser():
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--one_device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
+    ap.add_argument("--rank_timeout", type=float, default=1500.0,
+                    help="--gpus > 1 from a bare shell: seconds after which the launcher gives up and terminates every rank")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
     return ap
 
@@ -553,7 +532,7 @@ def main(argv=None):
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not under_launcher:
         # parent: nothing here may initialise the GPU (torch.cuda.is_available() would)
-        return launch_ranks(argv, args.gpus)
+        return launch_ranks(argv, args.gpus, rank_timeout=args.rank_timeout)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")

@@ -332,7 +332,8 @@ int hipac_linear_backward(const float* x, const float* w, const float* dy, const
                           float* dw, float* db, int M, int N, int K, int accumulate, void* stream);
 
 /* nn.CrossEntropyLoss(weight = class_w) value and gradient (src/main.py:490, :552-566): logits [M][C],
- * labels int64 [M], class_w [C] or NULL, loss float[1], dlogits [M][C], scratch float[2]; all device. */
+ * labels int64 [M], class_w [C] or NULL, loss float[1], dlogits [M][C], scratch float[2]; all device.
+ * A label outside [0, C) (torch raises there) is never dereferenced: the loss and that row's gradient come out NaN. */
 int hipac_cross_entropy_fwd_bwd(const float* logits, const int64_t* labels, const float* class_w, int M, int C,
                                 float* loss, float* dlogits, float* scratch, void* stream);
 

@@ -580,9 +580,14 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
       for (int j = 1; j < C; ++j) mx = fmaxf(mx, l[j]);
       float se = 0.f;
       for (int j = 0; j < C; ++j) se += expf(l[j] - mx);
-      const int y = (int)labels[m];
-      w = cw ? cw[y] : 1.f;
-      nll = w * (logf(se) + mx - l[y]);
+      const long long yl = labels[m];
+      if (yl < 0 || yl >= C) {  // torch raises here; no out-of-bounds read, and the loss comes out NaN
+        nll = __builtin_nanf(""), w = 0.f;
+      } else {
+        const int y = (int)yl;
+        w = cw ? cw[y] : 1.f;
+        nll = w * (logf(se) + mx - l[y]);
+      }
     }
     for (int o = 32; o > 0; o >>= 1) nll += __shfl_down(nll, o, 64), w += __shfl_down(w, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&scratch[0], nll), atomicAdd(&scratch[1], w);
@@ -592,8 +597,9 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     for (int j = 1; j < C; ++j) mx = fmaxf(mx, l[j]);
     float se = 0.f;
     for (int j = 0; j < C; ++j) se += expf(l[j] - mx);
-    const int y = (int)labels[m];
-    const float w = (cw ? cw[y] : 1.f) / scratch[1];
+    const long long yl = labels[m];
+    const int y = (yl < 0 || yl >= C) ? -1 : (int)yl;
+    const float w = y < 0 ? __builtin_nanf("") : (cw ? cw[y] : 1.f) / scratch[1];
     for (int j = 0; j < C; ++j) dlogits[(size_t)m * C + j] = w * (expf(l[j] - mx) / se - (j == y ? 1.f : 0.f));
     if (m == 0) loss[0] = scratch[0] / scratch[1];
   }
@@ -1008,7 +1014,9 @@ int hipac_cross_entropy_fwd_bwd(const float* logits, const int64_t* labels, cons
 int hipac_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int step, void* stream) {
   HIPAC_REQUIRE(params && grads && m && v && n > 0 && step >= 1, HIPAC_EINVAL, "adam: bad argument");
-  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = sqrtf(1.0f - powf(beta2, (float)step));
+  // bias corrections in double, as torch computes them with Python floats (1 - 0.999f in fp32 is 1.3e-5 off at step 1)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n, lr,
                      beta1, beta2, eps, bc1, bc2);
   HIPAC_CHECK_HIP(hipGetLastError());

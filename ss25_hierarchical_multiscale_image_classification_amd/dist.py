@@ -20,6 +20,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -95,6 +96,107 @@ def gather_results(feats: torch.Tensor, logits: Optional[torch.Tensor], meta: to
     """Collect every rank's per-patch rows on every rank (rank-major order)."""
     return (all_gather_rows(feats, group), all_gather_rows(logits, group) if logits is not None else None,
             all_gather_rows(meta, group))
+
+
+def rank_world() -> Tuple[int, int]:
+    """(rank, world) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def score_sharded(n_units: int, score_fn, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+    """BASELINE configs[3]: units (slides) sharded over the ranks (unit i -> rank i mod world), each scored by its
+    owner with ``score_fn(i) -> (feats[n_i,512], logits[n_i,C] or None, meta int32[n_i,4])``, one ragged all-gather of
+    every rank's rows, and the rows put back into UNIT order (a stable sort on the unit index, which travels as a fifth
+    meta column): every rank returns exactly what a single process scoring units 0, 1, 2, ... would have produced --
+    the order nn.DataParallel's gather gives the reference (src/main.py:841-842, :870).
+    Returns (feats, logits or None, meta int32[N,5] = level, x, y, label, unit)."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    fs, ls, ms = [], [], []
+    dev, n_cls = None, None
+    for i in shard_units(n_units, rank, world):
+        f, l, m = score_fn(i)
+        dev = f.device
+        fs.append(f)
+        if l is not None:
+            ls.append(l)
+            n_cls = l.shape[1]
+        ms.append(torch.cat([m.to(torch.int32), torch.full((m.shape[0], 1), i, dtype=torch.int32, device=m.device)], dim=1))
+    if dev is None:  # a rank without units still takes part in the exchange (as many columns as the others, zero rows)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    has_logits = torch.tensor([0 if n_cls is None else n_cls], dtype=torch.int64)
+    if world > 1:
+        lst = [torch.zeros_like(has_logits) for _ in range(world)]
+        dist.all_gather(lst, has_logits.to(dev) if dist.get_backend(group) == "nccl" else has_logits, group=group)
+        n_cls = max(int(t.item()) for t in lst) or None
+    feats = torch.cat(fs) if fs else torch.zeros((0, 512), dtype=torch.float32, device=dev)
+    logits = (torch.cat(ls) if ls else torch.zeros((0, n_cls), dtype=torch.float32, device=dev)) if n_cls else None
+    meta = torch.cat(ms) if ms else torch.zeros((0, 5), dtype=torch.int32, device=dev)
+    if world > 1:
+        feats, logits, meta = gather_results(feats, logits, meta, group)
+        order = torch.argsort(meta[:, 4], stable=True)
+        feats, meta = feats[order], meta[order]
+        logits = logits[order] if logits is not None else None
+    return feats, logits, meta
+
+
+def broadcast0(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place broadcast of rank 0's tensor (nn.DataParallel replicates the module of device 0 before every forward)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            h = t.cpu()
+            dist.broadcast(h, 0, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, 0, group=group)
+    return t
+
+
+def all_reduce_sum_scalars(values: Sequence[float], device=None) -> List[float]:
+    """Sum of a few host numbers over the ranks (loss and accuracy counters of the training loops)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return list(values)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t)
+    return [float(v) for v in t.cpu()]
+
+
+class RankBatchSampler(torch.utils.data.Sampler):
+    """Batch sampler of process-per-GPU training: every rank draws the SAME (seeded) permutation, cuts it into global
+    batches of ``batch_size`` and keeps its own contiguous share of each -- the chunk nn.DataParallel's scatter would
+    hand to replica ``rank`` (src/main.py:481-482).  Shares are equal on all ranks (the collectives need that), so up to
+    ``world - 1`` samples of a batch that does not divide are left out of that batch.  world == 1: plain batches."""
+
+    def __init__(self, n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 0):
+        self.n, self.batch_size, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, batch_size, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def _batches(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(self.n, generator=g).tolist()
+        else:
+            perm = list(range(self.n))
+        for b0 in range(0, self.n, self.batch_size):
+            idx = perm[b0:b0 + self.batch_size]
+            per = len(idx) // self.world
+            if per > 0:
+                yield idx[self.rank * per:(self.rank + 1) * per]
+
+    def __iter__(self):
+        it = self._batches()
+        self.epoch += 1  # a new permutation per pass, the same one on every rank
+        return it
+
+    def __len__(self):
+        full, rem = divmod(self.n, self.batch_size)
+        return full + (1 if rem // self.world > 0 else 0)
 
 
 class _GatherWithGrad(torch.autograd.Function):

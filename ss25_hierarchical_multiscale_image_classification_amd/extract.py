@@ -359,9 +359,11 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     with torch.cuda.stream(side), trace.span("window decisions, small levels"):
         lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in small]
         kepts = [lw.kept_index() for lw in lws]  # host syncs with the side stream only
+        # the meta rows are cut on the stream their inputs live on (a read from the caller's stream would sit behind
+        # the queued forwards and could outlive the tables); the caller's stream joins the side stream before the end
+        for lv, lw, k in zip(small, lws, kepts):
+            proc_meta[lv] = (lw.meta(k), int(k.shape[0]))
     n_small = sum(int(k.shape[0]) for k in kepts)
-    for lv, lw, k in zip(small, lws, kepts):
-        proc_meta[lv] = (lw.meta(k), int(k.shape[0]))
     carry = n_small % FWD if n_small else 0
     buf_s, mk_s = None, []
     if n_small:
@@ -377,8 +379,8 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     with torch.cuda.stream(side), trace.span(f"window decisions, level {big}"):
         lwb = LevelWindows(slide, big, stride_of(big))
         kb = lwb.kept_index()
+        proc_meta[big] = (lwb.meta(kb), int(kb.shape[0]))
     nb = int(kb.shape[0])
-    proc_meta[big] = (lwb.meta(kb), nb)
     if carry + nb:
         buf_b = torch.empty((carry + nb, 224, 224, 3), dtype=torch.uint8, device=dev)
         mk_b = []

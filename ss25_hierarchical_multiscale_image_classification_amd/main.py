@@ -12,7 +12,10 @@ the reference (patch_features_L.npy, patch_labels_L.npy, patch_paths_L.txt).
 
 Additive flags: ``--data_root``, ``--synthetic W,H,SEED[,NAME]`` (repeatable; a slide
 made on the GPU instead of a file), ``--write_png`` (also emit the reference's PNG
-tree), ``--precision {bf16,fp16,fp16x3,fp32}``, ``--weights PATH``, ``--stride N``.
+tree), ``--precision {bf16,fp16,fp16x3,fp32}``, ``--weights PATH``, ``--stride N``,
+``--world_size N`` (one process per GPU over RCCL where the reference wraps its model in
+nn.DataParallel, src/main.py:481-482, :841-842: ``--patch`` / ``--extract_features`` shard the
+slides, ``--train*`` the batches; started by this program itself before it touches a GPU).
 
 Everything outside the hot path (download, FROC, plots, MIL) is out of scope and the
 corresponding reference flags are accepted but answered with a clear message.
@@ -61,6 +64,16 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--simclr_encoder", type=str, default=None,
                    help="--extract_features with a SimCLR encoder checkpoint (extract_features_with_simclr, src/main.py:897-932)")
     p.add_argument("--batch_size", type=int, default=512)  # BATCH_SIZE, src/main.py:46
+    p.add_argument("--world_size", type=int, default=1,
+                   help="number of GPUs = processes (the reference uses every visible GPU through nn.DataParallel)")
+    p.add_argument("--dist_backend", default="nccl", help="process-group backend of --world_size > 1 (nccl = RCCL)")
+    p.add_argument("--one_device", action="store_true",
+                   help="rehearsal only: every rank uses cuda:0 (needs --dist_backend gloo; RCCL wants one GPU per rank)")
+    p.add_argument("--rank_timeout", type=float, default=None, help="--world_size > 1: give up after this many seconds")
+    p.add_argument("--seed", type=int, default=None, help="seed of the host-side random draws (dataset shuffles, model init); "
+                                                       "with --world_size > 1 every rank uses the same one (default 0 there)")
+    p.add_argument("--max_steps", type=int, default=None, help="bound the training loops (tests)")
+    p.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
     return p
 
 
@@ -72,39 +85,57 @@ def levels_of(args) -> List[int]:
     return [0, 1, 2, 3] if args.patch_level == "all" else [int(args.patch_level)]
 
 
-def open_slides(args):
-    """Yield DeviceSlide objects: synthetic specs first, then files in train/img."""
+def list_slides(args):
+    """[(name, opener)] of every slide in processing order -- synthetic specs first, then the files in train/img --
+    without loading any: ``opener()`` puts the slide into HBM (a rank opens only the slides it owns)."""
     from .extract import DeviceSlide, parse_annotation_xml
 
+    out = []
     for spec in args.synthetic:
         parts = spec.split(",")
         w, h, seed = int(parts[0]), int(parts[1]), int(parts[2])
-        yield DeviceSlide.synthetic(w, h, seed=seed, name=parts[3] if len(parts) > 3 else f"synthetic_{seed}")
+        name = parts[3] if len(parts) > 3 else f"synthetic_{seed}"
+        out.append((name, lambda w=w, h=h, seed=seed, name=name: DeviceSlide.synthetic(w, h, seed=seed, name=name)))
     img_dir = os.path.join(data_root(args), "train", "img")
     if not os.path.isdir(img_dir):
-        return
+        return out
     ann_dir = os.path.join(data_root(args), "train", "mask", "annotations")
-    for file in sorted(os.listdir(img_dir)):
-        stem, ext = os.path.splitext(file)
+
+    def open_file(path, stem, ext):
         if ext == ".npz":
-            z = np.load(os.path.join(img_dir, file))
+            z = np.load(path)
             levels = [torch.from_numpy(z[f"level{i}"]) for i in range(len(z.files)) if f"level{i}" in z.files]
             slide = DeviceSlide(levels, name=stem)
-        elif ext in (".tif", ".tiff"):
-            # tiled pyramidal TIFF / BigTIFF (the CAMELYON16 container): own reader, openslide is not needed
-            slide = DeviceSlide.from_tiff(os.path.join(img_dir, file), name=stem)
         else:
-            continue
+            # tiled pyramidal TIFF / BigTIFF (the CAMELYON16 container): own reader, openslide is not needed
+            slide = DeviceSlide.from_tiff(path, name=stem)
         xml = os.path.join(ann_dir, stem + ".xml")
         if os.path.exists(xml):
             slide.polygons = parse_annotation_xml(xml)
-        yield slide
+        return slide
+
+    for file in sorted(os.listdir(img_dir)):
+        stem, ext = os.path.splitext(file)
+        if ext in (".npz", ".tif", ".tiff"):
+            out.append((stem, lambda p=os.path.join(img_dir, file), stem=stem, ext=ext: open_file(p, stem, ext)))
+    return out
+
+
+def open_slides(args, rank: int = 0, world: int = 1):
+    """Yield (index, DeviceSlide) of the slides this rank owns (slide i -> rank i mod world)."""
+    from .dist import shard_units
+
+    slides = list_slides(args)
+    for i in shard_units(len(slides), rank, world):
+        yield i, slides[i][1]()
 
 
 def cmd_patch(args):
+    from .dist import rank_world
     from .extract import save_patch_pngs, scan_level
 
-    for slide in open_slides(args):
+    rank, world = rank_world()  # N > 1: every rank extracts the slides it owns; the outputs are per-slide directories
+    for _, slide in open_slides(args, rank, world):
         for level in levels_of(args):
             level_dir = os.path.join(data_root(args), "patches", f"level_{level}")
             save_dir = os.path.join(level_dir, slide.name)
@@ -138,7 +169,7 @@ def load_net(args, num_classes: Optional[int] = None):
 
 
 def cmd_extract_features(args):
-    from .features import extract_features_from_pngs, extract_features_from_slide, save_feature_files
+    from .features import extract_features_from_pngs, save_feature_files
 
     level = int(args.patch_level) if args.patch_level != "all" else 3  # src/main.py:1134
     if args.simclr_encoder:  # extract_features_with_simclr: UnifiedResNet(encoder checkpoint, classifier=False)
@@ -147,17 +178,36 @@ def cmd_extract_features(args):
     patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
     has_png = os.path.isdir(patch_dir) and any(
         f.endswith(".png") for _, _, fs in os.walk(patch_dir) for f in fs)
+    from .dist import rank_world, score_sharded
+    from .extract import score_slide
+
+    rank, world = rank_world()
     if has_png:
+        if world > 1 and rank == 0:
+            print("[INFO] PNG patch tree: scored by rank 0 (the fused slide path is the one that shards)")
+        if rank != 0:
+            return 0
         feats, labels, paths = extract_features_from_pngs(patch_dir, net, batch_size=args.batch_size)
     else:
-        fs, ls, ps = [], [], []
-        for slide in open_slides(args):
-            f, l, p = extract_features_from_slide(slide, net, level, stride=args.stride)
-            fs.append(f), ls.append(l), ps.extend(p)
-        if not fs:
+        # fused path: slides sharded over the ranks, one ragged all-gather, rows back in slide order -- the files rank 0
+        # writes are the single-process files (DataParallel's gather order, src/main.py:841-842, :870-893)
+        slides = list_slides(args)
+        if not slides:
             print(f"[ERROR] Patches must be extracted at level {level} before extracting features.")
             return 1
-        feats, labels, paths = torch.cat(fs), np.concatenate(ls), ps
+
+        def score(i):
+            f, _, _, meta = score_slide(slides[i][1](), net, levels=(level,), batch_windows=512, stride=args.stride,
+                                        want_logits=False)
+            return f, None, meta
+
+        f_all, _, meta = score_sharded(len(slides), score, rank, world)
+        if rank != 0:
+            return 0
+        m = meta.cpu().numpy()
+        feats, labels = f_all.cpu(), m[:, 3].astype(np.int64)
+        names = [slides[u][0] for u in m[:, 4]]
+        paths = [f"{n}/{n}_x{x}_y{y}_{'tumor' if lab else 'normal'}.png" for n, (x, y, lab) in zip(names, m[:, 1:4])]
     save_feature_files(level, feats.numpy(), labels, paths)
     print(f"[INFO] Features saved to patch_features_{level}.npy ({feats.shape[0]} patches)")
     return 0
@@ -172,16 +222,53 @@ def cmd_train(args, strategy: Optional[str]):
         print("[ERROR] Patches must be extracted before training.")
         return 1
     train_resnet_classifier(patch_dir, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size,
-                            precision=args.precision, simclr_epochs=args.simclr_epochs)
+                            precision=args.precision, simclr_epochs=args.simclr_epochs, max_steps=args.max_steps)
     return 0
 
 
+def _seed_everything(seed: int):
+    import random
+
+    random.seed(seed)
+    np.random.seed(seed & 0x7FFFFFFF)
+    torch.manual_seed(seed)
+
+
 def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
     for name in OUT_OF_SCOPE:
         if getattr(args, name):
             print(f"[ERROR] --{name} is outside the accelerated hot path (see DESIGN.md 'Out of scope').")
             return 2
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.world_size > 1 and not under_launcher:
+        # parent: start one fresh process per GPU and supervise them; nothing here may initialise the GPU
+        from . import launch
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # importable from any working directory
+        entry = ["-c", f"import sys; sys.path.insert(0, {root!r}); from {__package__}.main import main; sys.exit(main())"]
+        cmds = launch.child_commands(entry, argv, args.world_size, launch.free_port())
+        return launch.launch_ranks(cmds, rank_timeout=args.rank_timeout, name="main.py")
+    if under_launcher and int(os.environ["WORLD_SIZE"]) > 1:
+        from . import dist as hdist
+
+        rank, world, local = hdist.init_from_env(args.dist_backend)
+        if args.world_size not in (1, world):
+            print(f"[ERROR] --world_size {args.world_size} but WORLD_SIZE={world}")
+            return 2
+        torch.cuda.set_device(0 if args.one_device else local)
+        _seed_everything(0 if args.seed is None else args.seed)  # the same host-side draws on every rank
+    elif args.seed is not None:
+        _seed_everything(args.seed)
+    try:
+        return _dispatch(args)
+    finally:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+def _dispatch(args) -> int:
     rc = 0
     if args.patch:
         cmd_patch(args)

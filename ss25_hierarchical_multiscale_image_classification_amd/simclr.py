@@ -88,27 +88,43 @@ def get_simclr_transform():
 
 
 def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr: float = 1e-3, device: str = "cuda",
-                    num_workers: int = 8, out_dir: str = ".", max_steps: Optional[int] = None, verbose: bool = True):
+                    num_workers: int = 8, out_dir: str = ".", max_steps: Optional[int] = None, verbose: bool = True,
+                    final_path: Optional[str] = None):
     """src/models/simclr.py:68-124 with the step on the native kernels: PatchDataset(transform=None) ->
     SimCLRDataset(two augmented views) -> DataLoader(batch_size, shuffle) -> per batch
     ``z_i = model(x_i); z_j = model(x_j); loss = nt_xent_loss(z_i, z_j); backward; Adam(lr).step()``.
     Same bookkeeping: best-loss checkpoint ``simclr_encoder_best.pth``, early-stop check every 20 epochs
     (patience 20), ``simclr_encoder_epoch{N}.pth`` every 50 epochs, final ``simclr_encoder.pth`` -- all
-    SimCLRModel state_dicts (``encoder.*``, ``projector.*``).  ``max_steps`` (additive) bounds the run for tests.
+    SimCLRModel state_dicts (``encoder.*``, ``projector.*``).  ``max_steps`` (additive) bounds the run for tests;
+    ``final_path`` (additive) names the final checkpoint instead of ``out_dir/simclr_encoder.pth``.
+    Under ``main.py --world_size N`` (one process per GPU, the reference's nn.DataParallel at :77-78) every rank takes its
+    share of each global batch of ``batch_size`` view pairs, batch-norm statistics stay per replica, NT-Xent sees the
+    all-gathered projections and the gradients are all-reduced; rank 0 writes the checkpoints.
     Returns (SimCLRModel with the trained weights, list of per-epoch mean losses)."""
     from torch.utils.data import DataLoader
 
+    from .dist import RankBatchSampler, rank_world
     from .patch_dataset import PatchDataset
     from .simclr_dataset import SimCLRDataset
     from .train_native import NativeSimCLRTrainer
 
+    rank, world = rank_world()
     base = PatchDataset(patch_dir, transform=None)
-    loader = DataLoader(SimCLRDataset(base, transform=get_simclr_transform()), batch_size=batch_size, shuffle=True,
-                        num_workers=num_workers)
+    ds = SimCLRDataset(base, transform=get_simclr_transform())
+    if world > 1:
+        loader = DataLoader(ds, batch_sampler=RankBatchSampler(len(ds), batch_size, rank, world, True, 0), num_workers=num_workers)
+    else:
+        loader = DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=num_workers)
     dev = torch.device(device)
     model = SimCLRModel()
     trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=lr)
-    save = lambda name: torch.save(trainer.state_dict(), os.path.join(out_dir, name))
+    trainer.sync_from_rank0()
+    verbose = verbose and rank == 0
+
+    def save(name):
+        if rank == 0:
+            torch.save(trainer.state_dict(), name if os.path.isabs(name) or os.path.dirname(name) else os.path.join(out_dir, name))
+
     best_loss, no_improve, best_epoch, history, steps = float("inf"), 0, -1, [], 0
     for epoch in range(epochs):
         total, n_batches = 0.0, 0
@@ -136,7 +152,7 @@ def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr
             save(f"simclr_encoder_epoch{epoch+1}.pth")
         if max_steps is not None and steps >= max_steps:
             break
-    save("simclr_encoder.pth")
+    save(final_path if final_path else "simclr_encoder.pth")
     model.load_state_dict(trainer.state_dict())
     if verbose:
         print("[INFO] SimCLR pretraining complete.")

@@ -20,10 +20,16 @@ from .transforms import eval_transform, train_transform
 SAMPLES_PER_CLASS = 7480  # src/main.py:50
 
 
-def get_dataloaders(patch_dir: str, test_ratio: float = 0.2, batch_size: int = 512, balanced: bool = False):
+def get_dataloaders(patch_dir: str, test_ratio: float = 0.2, batch_size: int = 512, balanced: bool = False,
+                    rank: int = 0, world: int = 1, seed: int = 0):
     """src/main.py:412-470: slide-level split (random_state=42), tumour patches
-    augmented, normal patches not, validation set balanced with default_rng(42)."""
+    augmented, normal patches not, validation set balanced with default_rng(42).
+    ``world > 1`` (one process per GPU): every rank builds the same datasets (the caller seeds ``random`` identically on
+    all ranks) and draws its share of every global batch (``dist.RankBatchSampler``: the chunk DataParallel's scatter
+    gives replica ``rank``); the validation batches are shared out the same way, unshuffled."""
     from sklearn.model_selection import train_test_split
+
+    from .dist import RankBatchSampler
 
     slide_dirs = sorted(d for d in os.listdir(patch_dir) if os.path.isdir(os.path.join(patch_dir, d)))
     if len(slide_dirs) > 1:
@@ -42,8 +48,19 @@ def get_dataloaders(patch_dir: str, test_ratio: float = 0.2, batch_size: int = 5
         rng = np.random.default_rng(42)
         sel = np.concatenate([rng.choice(tum, n_min, replace=False), rng.choice(nor, n_min, replace=False)])
         val_ds = Subset(val_ds, sel)
+    if world > 1:
+        return (DataLoader(train_ds, batch_sampler=RankBatchSampler(len(train_ds), batch_size, rank, world, True, seed)),
+                DataLoader(val_ds, batch_sampler=_val_share(len(val_ds), batch_size, rank, world)), train_ds, val_ds)
     return (DataLoader(train_ds, batch_size=batch_size, shuffle=True),
             DataLoader(val_ds, batch_size=batch_size, shuffle=False), train_ds, val_ds)
+
+
+def _val_share(n: int, batch_size: int, rank: int, world: int):
+    """Validation indices of this rank (a contiguous range: every sample is scored exactly once), in batches."""
+    from .dist import shard_columns
+
+    i0, i1 = shard_columns(n, rank, world)
+    return [list(range(b, min(b + batch_size, i1))) for b in range(i0, i1, batch_size)]
 
 
 def class_weights(train_ds: PatchDataset, strategy: Optional[str]) -> Optional[torch.Tensor]:
@@ -71,20 +88,27 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     validation scores with the HIP inference path in ``precision``.  ``self_supervised``: pre-trains SimCLR when
     ``simclr_path`` does not exist (:556-557), then starts the classifier from that encoder -- what the reference
     means to do (its constructor call raises a TypeError there)."""
+    from .dist import all_reduce_sum_scalars, rank_world
     from .train_native import NativeClassifierTrainer
     from .weights import canonical_state_dict
 
+    rank, world = rank_world()  # > 1 under ``main.py --world_size N``: one process per GPU, global batch = batch_size
     epochs = epochs if epochs is not None else (30 if strategy is None else 5)  # :494 / :575
     train_loader, val_loader, train_ds, val_ds = get_dataloaders(patch_dir, 0.2, batch_size,
-                                                                 balanced=strategy == "balanced")
+                                                                 balanced=strategy == "balanced", rank=rank, world=world)
     dev = torch.device(device)
     model = ResNet18Classifier().set_precision(precision)
     if strategy == "self_supervised":
         if not os.path.exists(simclr_path):
             from .simclr import pretrain_simclr
 
+            # the final checkpoint goes to simclr_path itself, whatever its basename
             pretrain_simclr(patch_dir, epochs=simclr_epochs, batch_size=batch_size, device=device,
-                            out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps)
+                            out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps, final_path=simclr_path)
+            if world > 1:
+                torch.distributed.barrier()  # rank 0 wrote the file
+        if not os.path.exists(simclr_path):
+            raise FileNotFoundError(f"SimCLR encoder checkpoint {simclr_path} is missing after pre-training")
         enc = canonical_state_dict(torch.load(simclr_path, map_location="cpu", weights_only=True))
         sd = model.state_dict()
         for k, v in enc.items():  # encoder.* -> model.*; the projector is dropped, model.fc keeps its init
@@ -93,17 +117,19 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
         model.load_state_dict(sd)
     w = class_weights(train_ds, strategy)
     trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w)
+    trainer.sync_from_rank0()
     history, steps = [], 0
     for epoch in range(epochs):
         total, correct, seen = 0.0, 0, 0
         for imgs, labels, _ in train_loader:
             loss, logits = trainer.step(imgs.to(dev, torch.float32).contiguous(), labels)
-            total += float(loss)
+            total += float(loss)  # N > 1: already the loss of the global batch
             correct += int((logits.argmax(1).cpu() == labels).sum())
             seen += int(labels.numel())
             steps += 1
             if max_steps is not None and steps >= max_steps:
                 break
+        trainer.sync_from_rank0()  # N > 1: replica 0's running statistics are the module's (the others' updates are dropped)
         model.load_state_dict(trainer.state_dict())
         model.to(dev).eval()  # validation scoring on the HIP inference path (BN folded from the running statistics)
         v_correct, v_seen = 0, 0
@@ -112,9 +138,14 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
                 pred, _ = model.predict(imgs.to(dev))
                 v_correct += int((pred.cpu() == labels).sum())
                 v_seen += int(labels.numel())
-        history.append((total, correct / max(seen, 1), v_correct / max(v_seen, 1)))
-        print(f"Epoch {epoch+1}, Train Loss: {total:.4f}, Train Acc: {history[-1][1]:.4f}, Val Acc: {history[-1][2]:.4f}")
-        if strategy is None and (epoch + 1) % 10 == 0 and save_path is None:  # :528-531
+        correct, v_correct, v_seen = all_reduce_sum_scalars([correct, v_correct, v_seen], dev)  # counters over all ranks
+        # the reference divides the training hits by len(train_dataset) (src/main.py:514); that equals the samples
+        # seen unless max_steps cut the epoch short
+        n_train = len(train_ds) if (max_steps is None or steps < max_steps) else all_reduce_sum_scalars([seen], dev)[0]
+        history.append((total, correct / max(n_train, 1), v_correct / max(v_seen, 1)))
+        if rank == 0:
+            print(f"Epoch {epoch+1}, Train Loss: {total:.4f}, Train Acc: {history[-1][1]:.4f}, Val Acc: {history[-1][2]:.4f}")
+        if rank == 0 and strategy is None and (epoch + 1) % 10 == 0 and save_path is None:  # :528-531
             os.makedirs(os.path.join("src", "models"), exist_ok=True)
             torch.save(trainer.state_dict(), os.path.join("src", "models", f"resnet18_patch_classifier_epoch{epoch+1}.pth"))
         if max_steps is not None and steps >= max_steps:
@@ -122,7 +153,8 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     if save_path is None:
         name = "resnet18_patch_classifier.pth" if strategy is None else f"resnet18_patch_classifier_{strategy}.pth"
         save_path = os.path.join("src", "models", name)  # src/main.py:533 / :605
-    os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
-    torch.save(trainer.state_dict(), save_path)
+    if rank == 0:  # replica 0's parameters and running statistics are the module's (nn.DataParallel)
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+        torch.save(trainer.state_dict(), save_path)
     model.load_state_dict(trainer.state_dict())
     return model, history

@@ -276,6 +276,14 @@ class NativeSimCLRTrainer:
         _all_reduce_sum(self.head.grads)
         return loss
 
+    def sync_from_rank0(self):
+        """N > 1: every replica starts from rank 0's parameters and running statistics, as nn.DataParallel replicates
+        the module of device 0 (src/models/simclr.py:77-78)."""
+        from .dist import broadcast0
+
+        for t in (self.encoder.opt.params, self.encoder.stats, self.head.params):
+            broadcast0(t)
+
     def step(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
         loss = self.forward_backward(x_i, x_j)
         self.encoder.opt.step()
@@ -313,20 +321,38 @@ class NativeClassifierTrainer:
         self._scratch = torch.zeros(2, dtype=torch.float32, device=self.device)
 
     def forward_backward(self, x: torch.Tensor, labels: torch.Tensor):
+        """(loss, logits of this rank).  N > 1: the loss is CrossEntropyLoss(weight) over the GLOBAL batch, as the
+        reference evaluates it on nn.DataParallel's gathered logits (src/main.py:499-506): sum_i w_i nll_i over all
+        ranks / sum_i w_i over all ranks.  Logits and labels are all-gathered (2 + 1 numbers per image), every rank
+        evaluates the same loss and keeps its own rows of the gradient, so the SUM all-reduce of the parameter
+        gradients below is exactly the gradient of that global loss."""
+        C_ = int(self.fc.w.shape[0])
+        if not labels.is_cuda and (int(labels.min()) < 0 or int(labels.max()) >= C_):
+            raise capi.HipacError(f"cross_entropy: label outside [0, {C_}) (torch raises an IndexError here)")
         f = self.encoder.forward(x, slot=0)
         logits = self.fc.forward(f)
         loss = torch.empty((), dtype=torch.float32, device=self.device)
-        dlogits = torch.empty_like(logits)
         labels = labels.to(self.device, torch.int64).contiguous()
+        L, r0 = _all_gather_rows(logits)
+        Y, _ = _all_gather_rows(labels)
+        dL = torch.empty_like(L)
         with torch.cuda.device(self.device):
             capi._check(capi.load_library().hipac_cross_entropy_fwd_bwd(
-                logits.data_ptr(), labels.data_ptr(), capi._ptr(self.class_weights), logits.shape[0], logits.shape[1],
-                loss.data_ptr(), dlogits.data_ptr(), self._scratch.data_ptr(), capi._stream()), "hipac_cross_entropy_fwd_bwd")
+                L.data_ptr(), Y.data_ptr(), capi._ptr(self.class_weights), L.shape[0], L.shape[1],
+                loss.data_ptr(), dL.data_ptr(), self._scratch.data_ptr(), capi._stream()), "hipac_cross_entropy_fwd_bwd")
+        dlogits = dL[r0:r0 + logits.shape[0]].contiguous()
         df = self.fc.backward(f, logits, dlogits, accumulate=False)
         self.encoder.backward(df, slot=0, accumulate=False)
         _all_reduce_sum(self.encoder.opt.grads)
         _all_reduce_sum(self.head.grads)
         return loss, logits
+
+    def sync_from_rank0(self):
+        """N > 1: every replica starts from rank 0's parameters and running statistics (src/main.py:481-482)."""
+        from .dist import broadcast0
+
+        for t in (self.encoder.opt.params, self.encoder.stats, self.head.params):
+            broadcast0(t)
 
     def step(self, x: torch.Tensor, labels: torch.Tensor):
         loss, logits = self.forward_backward(x, labels)

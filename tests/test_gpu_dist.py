@@ -1,0 +1,124 @@
+"""Multi-rank paths on the GPU box (one MI355X: both ranks on cuda:0, gloo process group -- RCCL wants one GPU per rank
+and is first exercised by the driver's 8-GPU run): BASELINE configs[3] (slides sharded over the ranks, one ragged
+all-gather), the product CLI's --world_size launcher, and the classifier step's global weighted cross-entropy."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from ss25_hierarchical_multiscale_image_classification_amd import capi, extract, launch, synth
+
+pytestmark = pytest.mark.gpu
+HELPERS = os.path.join(os.path.dirname(__file__), "helpers")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(helper, args, n=2, timeout=900):
+    cmds = launch.child_commands([os.path.join(HELPERS, helper)], args, n, launch.free_port())
+    procs = [subprocess.Popen(cmd[:-1], env=env) for cmd, env in cmds]  # (the helpers take no --_child flag)
+    assert [p.wait(timeout=timeout) for p in procs] == [0] * n
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16"])
+def test_two_rank_sharded_slides_equal_single_process(tmp_path, precision):
+    """configs[3] in miniature: 3 synthetic slides, slide i -> rank i mod 2 (`dist.shard_units`), `extract.score_slide`
+    per slide, `dist.gather_results`.  The rank-major result is the single-process result of slides (0, 2, 1) bit for
+    bit -- features, logits and meta -- on both ranks; `dist.score_sharded` (what `main.py --world_size` calls) returns
+    the rows in slide order 0, 1, 2 = exactly the single-process output."""
+    specs = [[1500, 1300, 31], [1250, 1400, 32], [1600, 1100, 33]]
+    torch.save(torch.tensor(specs), tmp_path / "specs.pt")
+    _run_ranks("wsi_rank.py", [str(tmp_path), precision])
+    net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision=precision)
+    single = []
+    for i, (w, h, seed) in enumerate(specs):
+        slide = extract.DeviceSlide.synthetic(w, h, seed=seed, name=f"slide_{i}", with_polygons=True)
+        f, l, _, meta = extract.score_slide(slide, net, levels=(1, 2, 3), fwd_batch=64)
+        single.append((f.cpu(), l.cpu(), meta.cpu()))
+    assert all(s[0].shape[0] > 0 for s in single)
+    res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2)]
+    for r in range(2):
+        gf, gl, gm = res[r]["rank_major"]
+        order = (0, 2, 1)  # rank 0 owns slides 0 and 2, rank 1 slide 1
+        assert torch.equal(gf, torch.cat([single[i][0] for i in order]))
+        assert torch.equal(gl, torch.cat([single[i][1] for i in order]))
+        assert torch.equal(gm, torch.cat([single[i][2] for i in order])), (gm.tolist(), [single[i][2].tolist() for i in order])
+        sf, sl, sm = res[r]["slide_order"]
+        assert torch.equal(sf, torch.cat([s[0] for s in single])) and torch.equal(sl, torch.cat([s[1] for s in single]))
+        assert torch.equal(sm[:, :4], torch.cat([s[2] for s in single])), (r, sm.tolist(), gm.tolist())
+        assert sm[:, 4].tolist() == sum(([i] * single[i][0].shape[0] for i in range(3)), [])
+
+
+def test_cli_world_size_writes_the_single_process_files(tmp_path):
+    """`main.py --extract_features --world_size 2` (the launcher starts two fresh ranks; here both on cuda:0 over gloo):
+    the three files rank 0 writes are byte-identical to those of the single-process run."""
+    outs = []
+    for world in (1, 2):
+        d = tmp_path / f"w{world}"
+        d.mkdir()
+        cmd = [sys.executable, os.path.join(ROOT, "src", "main.py"), "--extract_features", "--patch_level", "1", "--precision",
+               "fp16", "--data_root", str(d / "none"), "--synthetic", "2600,2300,41,tumor_041", "--synthetic",
+               "2300,2500,42,normal_042", "--synthetic", "2400,2400,43,tumor_043"]
+        if world > 1:
+            cmd += ["--world_size", "2", "--dist_backend", "gloo", "--one_device", "--rank_timeout", "600"]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(d)
+    f1, f2 = np.load(outs[0] / "patch_features_1.npy"), np.load(outs[1] / "patch_features_1.npy")
+    assert f1.shape[0] > 10 and np.array_equal(f1, f2)
+    assert np.array_equal(np.load(outs[0] / "patch_labels_1.npy"), np.load(outs[1] / "patch_labels_1.npy"))
+    assert (outs[0] / "patch_paths_1.txt").read_text() == (outs[1] / "patch_paths_1.txt").read_text()
+
+
+def test_cli_world_size_reports_a_failing_rank(tmp_path):
+    """A rank that dies takes the run down at once with its exit code (no hang in the rendezvous)."""
+    cmd = [sys.executable, os.path.join(ROOT, "src", "main.py"), "--extract_features", "--weights", str(tmp_path / "missing.pth"),
+           "--synthetic", "1300,1300,5", "--world_size", "2", "--dist_backend", "gloo", "--one_device"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "exited with code" in r.stderr
+
+
+def test_two_rank_classifier_step(tmp_path):
+    """Two ranks, 4 images each, class weights (1, 2.5) and DIFFERENT class mixes per rank: the loss both ranks report
+    and the gradients after the SUM all-reduce are those of CrossEntropyLoss(weight) over the gathered logits -- sum_i
+    w_i nll_i / sum_i w_i over ALL ranks, as the reference evaluates it under nn.DataParallel (src/main.py:499-506)."""
+    import torch.nn.functional as F
+
+    from oracle import train_ref as TR
+    from oracle.resnet18_ref import canonical_state_dict
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier
+
+    torch.manual_seed(29)
+    model = ResNet18Classifier()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 4, 3, 224, 224)
+    y = torch.tensor([[0, 0, 0, 1], [1, 1, 0, 1]])
+    w = torch.tensor([1.0, 2.5])
+    torch.save(sd, tmp_path / "sd.pt")
+    torch.save({"x": x, "y": y, "w": w}, tmp_path / "xy.pt")
+    _run_ranks("classifier_rank.py", [str(tmp_path)])
+    res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2)]
+    assert res[0]["loss"] == res[1]["loss"]
+    for k, g in res[0]["grads"].items():
+        assert torch.equal(g, res[1]["grads"][k]), k
+    # oracle: each replica's images through the encoder separately (per-replica batch statistics), ONE loss
+    bare = canonical_state_dict(sd)
+    p, _ = TR._split(bare)
+    logits = []
+    for r in range(2):
+        _, st = TR._split(bare)
+        logits.append(F.linear(TR.encoder_train_forward(x[r], p, st), p["fc.weight"], p["fc.bias"]))
+    loss = F.cross_entropy(torch.cat(logits), y.reshape(-1), weight=w)
+    loss.backward()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert abs(res[0]["loss"] - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-6
+    for r in range(2):
+        assert rel(res[r]["logits"], logits[r].detach()) <= 1e-4
+    # the gradients nearest to the loss carry the normalisation (deep layers flip ReLU patterns, see test_gpu_train.py)
+    for k in ("fc.weight", "fc.bias"):
+        assert rel(res[0]["grads"][k], p[k].grad) <= 5e-3, (k, rel(res[0]["grads"][k], p[k].grad))
+    # and it is NOT the per-rank-normalised sum the round-2 code computed (about world x larger)
+    local = sum(F.cross_entropy(l.detach(), y[r], weight=w) for r, l in enumerate(logits))
+    assert abs(float(local) - float(loss)) > 1e-3
