@@ -342,7 +342,9 @@ def run_resnet(args, rank, world, dev):
                           "ms": round(o["ms"], 4), "tflops": None if o["tflops"] is None else round(o["tflops"], 1),
                           "frac": None if o["tflops"] is None else round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3)} for o in ops]
         if traffic is not None:
-            rec["roofline"]["traffic_source"] = "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            tj = json.load(open(tpath))
+            rec["roofline"]["traffic_source"] = ("profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), "
+                                                 f"collected at commit {tj.get('_commit', 'unrecorded')}: stale if that kernel changed since")
     nets = {args.precision: net}
     if rank == 0 and world == 1:
         # the same kernels instantiated for the other operand type, and the exact f32 MFMA parity mode
@@ -397,6 +399,18 @@ def run_resnet(args, rank, world, dev):
             rec["parity"] = parity_block(nets, u8_256, ref)
     del data
     torch.cuda.empty_cache()
+    if not args.no_simclr and world == 1 and rank == 0:
+        # configs[4], bounded: the native SimCLR step on 2 x 256 views, a few steps (the full 2 x 1024 is
+        # `--workload simclr`); same record as that workload, with its roofline
+        import argparse as _ap
+
+        from ss25_hierarchical_multiscale_image_classification_amd import train_native
+        try:
+            sargs = _ap.Namespace(simclr_views=256, warmup=1, steps=3)
+            rec["simclr"] = train_native.bench_simclr_step(sargs, rank, world, dev)
+        except (RuntimeError, capi.HipacError) as e:
+            rec["simclr"] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
     if not args.no_wsi:
         sides = [int(s) for s in args.wsi_sides.split(",") if s]
         if world > 1:
@@ -513,6 +527,7 @@ def build_parser():
     ap.add_argument("--slide_side", type=int, default=50000)
     ap.add_argument("--wsi_sides", default="50000,100000", help="slide sides of the `wsi` object of the default line")
     ap.add_argument("--no_wsi", action="store_true", help="default workload: skip the `wsi` object")
+    ap.add_argument("--no_simclr", action="store_true", help="default workload: skip the bounded `simclr` object (configs[4])")
     ap.add_argument("--grid", choices=["reference", "nonoverlap"], default="reference")
     ap.add_argument("--batch_windows", type=int, default=4096)
     ap.add_argument("--simclr_views", type=int, default=1024, help="simclr: images per view per step, over all ranks")

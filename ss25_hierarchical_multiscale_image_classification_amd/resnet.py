@@ -5,8 +5,12 @@ layouts as the reference, so a script written against ``src/models/resnet.py`` k
 working.  What changes is what runs: in ``eval()`` mode on a ROCm device ``forward``
 hands the batch to the hand-written HIP path (libhipac_hip.so) -- BN folded, MFMA
 implicit-GEMM convolutions -- and there is NO CPU fallback: a CPU tensor in eval mode
-raises.  In ``train()`` mode the module runs its ordinary autograd graph (the native
-training step is the "next" row of SURVEY.md section 8).
+raises.  TRAINING is native as well, but not through ``forward``: the step (train-mode forward,
+backward, loss, Adam) is one chain of launches behind ``train_native.NativeClassifierTrainer`` /
+``NativeSimCLRTrainer``, driven by ``train.train_resnet_classifier`` and ``simclr.pretrain_simclr``.
+A ``train()``-mode ``forward`` on a ROCm tensor therefore RAISES with that pointer instead of silently
+running a torch-autograd graph on the GPU; on a CPU tensor it runs the module's own parameter tree
+under torch autograd -- the graph tests/test_oracle_train.py pins the training oracle on.
 
 torchvision is not a dependency: ``ResNet18Graph`` declares the same parameter tree
 (and therefore the same key names) as ``torchvision.models.resnet18``.  Nothing is
@@ -97,11 +101,21 @@ class _HipBacked(nn.Module):
         self.precision = precision
         return self
 
+    def _train_guard(self, x: torch.Tensor) -> None:
+        """train()-mode forward: CPU tensors run the torch graph (the oracle's pin); a ROCm tensor would be a second,
+        non-native GPU path a caller could land on without noticing -- refuse it and name the native one."""
+        if x.is_cuda and os.environ.get("HIPAC_ALLOW_TORCH_AUTOGRAD", "0") != "1":
+            raise capi.HipacError(
+                f"{type(self).__name__}.forward in train() mode on a ROCm tensor: training runs on the native step, not "
+                "through forward -- use train.train_resnet_classifier / simclr.pretrain_simclr (or "
+                "train_native.NativeClassifierTrainer / NativeSimCLRTrainer with this module's state_dict()); call .eval() "
+                "for inference.  (HIPAC_ALLOW_TORCH_AUTOGRAD=1 runs the torch-autograd graph anyway.)")
+
     def _hip_forward(self, x: torch.Tensor, want: str) -> torch.Tensor:
         if not x.is_cuda:
             raise capi.HipacError(
                 "eval-mode forward got a CPU tensor: the HIP path has no CPU fallback "
-                "(move the batch to a ROCm device, or call .train() for the autograd graph)"
+                "(move the batch to a ROCm device)"
             )
         native = x.dim() == 4 and tuple(x.shape[1:]) == (capi.PAD_H, capi.PAD_W, 4)
         if not native:
@@ -126,6 +140,7 @@ class ResNet18FeatureExtractor(_HipBacked):
 
     def forward(self, x):
         if self.training:
+            self._train_guard(x)
             y = self.features(x)
             return y.view(y.size(0), -1)
         return self._hip_forward(x, "feats")
@@ -148,6 +163,7 @@ class UnifiedResNet(_HipBacked):
 
     def forward(self, x):
         if self.training:
+            self._train_guard(x)
             return self.model(x)
         return self._hip_forward(x, "logits" if self.classifier else "feats")
 
@@ -168,6 +184,7 @@ class ResNet18Classifier(_HipBacked):
 
     def forward(self, x):
         if self.training:
+            self._train_guard(x)
             return self.model(x)
         return self._hip_forward(x, "logits")
 
@@ -195,5 +212,6 @@ class ResNet18ClassifierSIMCLR(_HipBacked):
 
     def forward(self, x):
         if self.training:
+            self._train_guard(x)
             return self.encoder(x)
         return self._hip_forward(x, "logits")

@@ -8,7 +8,8 @@ forward / backward, projector, NT-Xent, Adam: csrc/train.hip, csrc/ntxent.hip) a
 only for the initial weights and the checkpoint format.  ``nt_xent_loss`` is the loss exactly as the
 reference defines it, with an optional ``gather`` hook so a process-per-GPU run sees the GLOBAL batch
 of negatives as nn.DataParallel does in the reference (src/models/simclr.py:88-95); the
-module's own ``forward`` in train mode (an ordinary autograd graph) is kept for scripts that call it.
+module's own ``forward`` in train mode runs the torch graph on CPU tensors only (the graph the training oracle is
+pinned on) and raises on a ROCm tensor with a pointer to the native step (resnet._HipBacked._train_guard).
 """
 from __future__ import annotations
 
@@ -36,6 +37,7 @@ class SimCLRModel(_HipBacked):
 
     def forward(self, x):
         if self.training:
+            self._train_guard(x)
             return self.projector(self.encoder(x))
         feats = self._hip_forward(x, "feats")
         return self.projector(feats)

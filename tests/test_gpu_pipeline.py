@@ -164,6 +164,48 @@ def test_cli_patch_then_extract_features(tmp_path, monkeypatch):
     assert np.isfinite(feats).all() and float(np.abs(feats).max()) > 0
 
 
+def test_cli_extract_features_with_simclr_encoder(tmp_path, monkeypatch):
+    """`--extract_features --simclr_encoder CKPT` (extract_features_with_simclr, src/main.py:897-932): the encoder of a
+    SimCLRModel checkpoint (`encoder.*`, projector dropped, fc = Identity) scores the patches -- the features equal a
+    direct forward of that encoder, and differ from those of the default seeded weights."""
+    from ss25_hierarchical_multiscale_image_classification_amd.main import main
+    from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel
+    from ss25_hierarchical_multiscale_image_classification_amd.weights import canonical_state_dict
+
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(77)
+    sim = SimCLRModel()
+    ckpt = tmp_path / "simclr_encoder.pth"
+    torch.save(sim.state_dict(), ckpt)
+    spec = ["--synthetic", "1500,1300,33,normal_042", "--data_root", str(tmp_path / "none")]
+    assert main(["--extract_features", "--patch_level", "1", "--precision", "fp16", "--simclr_encoder", str(ckpt)] + spec) == 0
+    feats = np.load(tmp_path / "patch_features_1.npy")
+    bare = {k: v for k, v in canonical_state_dict(sim.state_dict()).items() if not k.startswith(("projector.", "fc."))}
+    net = capi.PackedResNet18(bare, precision="fp16")
+    slide = extract.DeviceSlide.synthetic(1500, 1300, seed=33, name="normal_042")
+    ref, _, _ = features.extract_features_from_slide(slide, net, 1)
+    assert feats.shape == tuple(ref.shape) and feats.shape[0] > 1 and np.array_equal(feats, ref.numpy())
+    assert main(["--extract_features", "--patch_level", "1", "--precision", "fp16"] + spec) == 0  # seeded default weights
+    assert not np.allclose(np.load(tmp_path / "patch_features_1.npy"), feats, atol=1e-3)
+
+
+def test_train_mode_forward_on_gpu_points_to_the_native_step():
+    """No silent torch-autograd path on the GPU: a train()-mode forward on a ROCm tensor raises and names the native
+    trainers; on a CPU tensor it is the torch graph the training oracle is pinned on; eval() runs the HIP path."""
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier, ResNet18FeatureExtractor
+    from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel
+
+    x = torch.randn(2, 3, 224, 224)
+    for m in (ResNet18Classifier(), ResNet18FeatureExtractor(weight_path=None), SimCLRModel()):
+        m = m.cuda().train()
+        with pytest.raises(capi.HipacError, match="NativeClassifierTrainer"):
+            m(x.cuda())
+        assert m.cpu()(x).shape[0] == 2  # CPU tensor: the module's own graph
+        m = m.cuda().eval()
+        with torch.no_grad():
+            assert m(x.cuda()).shape[0] == 2
+
+
 def test_tiff_slide_scans_like_the_same_pixels_from_memory(tmp_path):
     # a tiled (deflate, lossless) TIFF pyramid read through tiff_pyramid -> DeviceSlide.from_tiff gives the
     # same extractor decisions and resized patches as the same levels handed over as tensors
