@@ -609,9 +609,11 @@ constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) 
 // with no workgroup barrier; workgroups are persistent and the next tile's band is prefetched
 // behind the epilogue.
 // SPLIT: fp16 (hi, lo) pairs, see conv_glds_kernel; virtual chunk 3c + 1 (Wlo x Xhi) reuses the band of 3c.
+// WM_ x WN_ = the 4 waves as pixel parts x channel parts; MINW = waves per SIMD the register budget is set for (1: one
+// 512-register wave per SIMD with a 128 x 128 tile -- 0.5 LDS fragment reads per MFMA instead of 0.75).
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32,
-          bool SPLIT = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+          bool SPLIT = false, int WM_ = 2, int WN_ = 2, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                               const float* __restrict__ bias,
                                                               const T* __restrict__ resid, void* __restrict__ outp,
                                                               int M, int n_img, int n_mtiles,
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   constexpr int OPIX = SPLIT ? 2 * COUT : COUT;     // elements per pixel of T-typed outputs and of the residual
   constexpr int KTOT = 9 * VCIN;
   static_assert(!SPLIT || std::is_same<T, _Float16>::value, "split pairs are fp16");
-  constexpr int WM = 2, WN = 2;                     // 4 waves: 2 pixel halves x 2 channel halves
+  constexpr int WM = WM_, WN = WN_;                 // 4 waves: pixel parts x channel parts
+  static_assert(WM * WN == 4, "four waves");
   constexpr int MTW = BM / (WM * 32);               // 32-pixel sub-tiles per wave (2 or 4)
   constexpr int WTN = BN / WN, NT = WTN / 32;       // channels per wave, 32-wide tiles per wave
   constexpr int A_PIECES = halo_band_pieces(W, BM);
@@ -634,12 +637,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
   constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
   constexpr int NTILES_N = COUT / BN;
   constexpr int NSTEP = 9 * CC;
-  static_assert((BM == 128 || BM == 256) && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
+  static_assert((BM == 128 || BM == 256 || BM == 512) && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
   static_assert((BN / 8) % 4 == 0, "W piece split");
   static_assert(NSW == 2 || NSW == 3, "weight ring depth");
   constexpr int STG_BYTES = 4 * 32 * (WTN * 4 + 16);  // 4 waves x [32 px][WTN fp32 + pad] epilogue staging
   constexpr int S_BYTES = NSW * W_BYTES > STG_BYTES ? NSW * W_BYTES : STG_BYTES;  // ring, aliased by the staging
-  static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
+  static_assert(A_BYTES + S_BYTES <= 160 * 1024 / MINW, "LDS: MINW workgroups per CU");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   unsigned char* const Abuf = ring;
@@ -2294,6 +2297,9 @@ static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
 #ifndef HIPAC_HALO_BM256
 #define HIPAC_HALO_BM256 1
 #endif
+#ifndef HIPAC_HALO_BIG
+#define HIPAC_HALO_BIG 0  // 1: layers 2-4 on one 512-register wave per SIMD (128 x 128 per wave)
+#endif
 #ifndef HIPAC_USE_C64
 #define HIPAC_USE_C64 1
 #endif
@@ -2337,6 +2343,24 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     const int grid = n_units < 512 ? n_units : 512;  // persistent, 2 workgroups per CU
     hipLaunchKernelGGL((conv3x3_c64_kernel<T, RESID>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w,
                        w.bias, (const T*)resid, (T*)out, n_tiles, zero_page);
+  } else if constexpr (HIPAC_USE_HALO && HIPAC_HALO_BIG && !SPLIT && KS == 3 && STRIDE == 1 && COUT >= 128) {
+    // one 512-register wave per SIMD, each wave a 128 pixel x 128 channel tile
+    constexpr int BN = COUT >= 256 ? 256 : 128;
+    constexpr int WM = COUT >= 256 ? 2 : 4, WN = 4 / WM;
+    constexpr int BM = WM * 128;
+    constexpr int A_BYTES = halo_band_pieces(WI, BM) * 1024;
+    constexpr int STG = 4 * 32 * (BN / WN * 4 + 16);
+    constexpr int NSW = (A_BYTES + (3 * BN * 128 > STG ? 3 * BN * 128 : STG) <= 160 * 1024) ? 3 : 2;
+    constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
+    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, false, WM, WN, 1>;
+    static bool attr_done[kMaxDevices] = {};
+    if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+    const int n_mtiles = (M + BM - 1) / BM;
+    const int mt8 = (n_mtiles + 7) / 8 * 8;
+    const int n_vtiles = mt8 * (COUT / BN);
+    dim3 grid(n_vtiles < 256 ? n_vtiles : 256);  // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
+                       n_mtiles, zero_page);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
     constexpr int BN = COUT >= 128 ? 128 : 64;
     // 256-pixel tiles (each wave 128 px x 64 ch: 0.75 LDS reads per MFMA, half the weight DMA per
