@@ -286,6 +286,17 @@ class PackedResNet18:
             self._lib.hipac_weights_free(h)
             self.handle = None
 
+    def batch_buffer(self, n: int, device: torch.device) -> torch.Tensor:
+        """uint8[n,224,224,3] view of a grow-only buffer kept on the handle (a whole slide's kept windows: multi-GB;
+        allocating it per slide would go through hipMalloc whenever the caching allocator had let go of the block).
+        Valid until the next call; a consumer on another stream must order itself after the forwards that read it."""
+        need = n * PATCH * PATCH * 3
+        buf = getattr(self, "_batch", None)
+        if buf is None or buf.numel() < need or buf.device != device:
+            self._batch = None  # release before growing
+            buf = self._batch = torch.empty(need, dtype=torch.uint8, device=device)
+        return buf[:need].view(n, PATCH, PATCH, 3)
+
     def workspace(self, batch: int, device: torch.device) -> torch.Tensor:
         need = self._lib.hipac_resnet18_workspace_bytes(batch, PRECISIONS[self.precision])
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
@@ -310,10 +321,10 @@ class PackedResNet18:
             if tuple(x.shape[1:]) != (PATCH, PATCH, 3):
                 raise HipacError(f"uint8 input must be [B,224,224,3], got {tuple(x.shape)}")
             layout = IN_U8_HWC
-            if self.precision == "fp32":  # parity mode has no fused uint8 stem: normalise first (bit-exact LUT)
+            if self.precision == "fp32":  # the debugging mode has no fused uint8 stem: normalise first (bit-exact LUT)
                 # the staging buffer is kept on the object (grow-only), like the workspace: a multi-GB block freed
                 # here while the kernels that read it are still queued could be handed to a caller that fills
-                # its next batch buffer from ANOTHER stream (extract.score_slide does)
+                # its next buffer from ANOTHER stream
                 n_el = x.shape[0] * 3 * PATCH * PATCH
                 if self._stage is None or self._stage.numel() < n_el or self._stage.device != x.device:
                     self._stage = torch.empty(n_el, dtype=torch.float32, device=x.device)

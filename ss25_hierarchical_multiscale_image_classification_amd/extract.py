@@ -307,107 +307,56 @@ class WSIPatchStream:
 def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[int] = (0, 1, 2, 3),
                 batch_windows: int = 4096, stride=None, want_logits: bool = True, fwd_batch: int = 8192):
     """Whole-slide hierarchical scan: windows -> whiteness/labels -> resize -> ResNet18 ->
-    per-patch features / logits / labels.  The kept windows of ALL requested levels are scored
-    in large batches (the late ResNet layers need thousands of patches per launch to fill the
-    chip; ``fwd_batch`` patches per forward).  ``stride``: None (reference: 224), an int, or a callable level -> stride.
+    per-patch features / logits / labels.  ``stride``: None (reference: 224), an int, or a callable level -> stride.
     Returns device tensors (feats[n,512], logits[n,C] or None, pred int64[n] or None,
-    meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order."""
+    meta int32[n,4] = (level, x, y, label)) in level-major, reference visiting order.
+
+    Three phases on the caller's stream, ONE wait of the host per slide:
+      1. the extractor's decisions for every requested level (whole-level kernels: resample planes, whiteness sums,
+         keep flags, labels) -- queued back to back, then the host reads the four kept counts;
+      2. the kept windows of all levels gathered, level-major, into ONE uint8 batch buffer (cached on ``net``, grow-only:
+         no multi-GB allocation per slide);
+      3. the ResNet over that buffer in slices of ``fwd_batch`` patches (the late layers need thousands of patches per
+         launch to fill the chip), results already in output order.
+    Measured on a 50 000^2 slide (tools/wsi_phases.py): 5 + 2.4 + 136 ms -- the scan IS the ResNet; running the level-0
+    decisions on a side stream underneath the first forwards (rounds 1-2) bought nothing (143 vs 144 ms: concurrent
+    kernels slow the persistent-grid convolutions down by what they hide) and cost a cross-stream lifetime race."""
     has_fc = net.num_classes > 0 and want_logits
     dev = slide.device
     levels = list(levels)
-    FWD = max(1, int(fwd_batch))  # patches per forward: the late layers need thousands of patches per launch
+    FWD = max(1, int(fwd_batch))
 
     def stride_of(level):
         return stride(level) if callable(stride) else stride
 
-    # Schedule: the level with the most windows (normally level 0) costs most to decide and gather, so
-    # the OTHER levels go first: their windows are decided (whole-level kernels), gathered into one uint8
-    # batch buffer on a side stream and the ResNet starts on them on the caller's stream; the big level's
-    # decisions and gathers then run on the side stream underneath those forwards.  Batches are zero-copy
-    # slices of the batch buffers; results are put back into level-major order at the end.
-    big = max(levels, key=lambda lv: slide.level_dimensions[lv][0] * slide.level_dimensions[lv][1])
-    small = [lv for lv in levels if lv != big]
-    main = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev)
-    side.wait_stream(main)
-    out_chunks = []   # (f, l, p) per forward, processing order
-    proc_meta = {}    # level -> (meta rows, count), to restore level-major order
-    marks = []        # per buffer: list of (patches gathered so far, event)
-
-    def gather_into(buf, start, lw, kept, mk):
-        done = start
-        for i0 in range(0, kept.shape[0], batch_windows):
-            idx = kept[i0:i0 + batch_windows]
-            lw.patches(idx, out=buf[done:done + idx.shape[0]])
-            done += idx.shape[0]
-            ev = torch.cuda.Event()
-            ev.record(side)
-            mk.append((done, ev))
-        return done
-
-    def forward_range(buf, mk, lo, hi):
-        mi = 0
-        while lo < hi:
-            end = min(hi, lo + FWD)
-            while mk[mi][0] < end:
-                mi += 1
-            main.wait_event(mk[mi][1])
-            with trace.span(f"resnet18 forward [{lo}:{end})"):
-                out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
-            lo = end
-
-    with torch.cuda.stream(side), trace.span("window decisions, small levels"):
-        lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in small]
-        kepts = [lw.kept_index() for lw in lws]  # host syncs with the side stream only
-        # the meta rows are cut on the stream their inputs live on (a read from the caller's stream would sit behind
-        # the queued forwards and could outlive the tables); the caller's stream joins the side stream before the end
-        for lv, lw, k in zip(small, lws, kepts):
-            proc_meta[lv] = (lw.meta(k), int(k.shape[0]))
-    n_small = sum(int(k.shape[0]) for k in kepts)
-    carry = n_small % FWD if n_small else 0
-    buf_s, mk_s = None, []
-    if n_small:
-        # allocated on the caller's stream and released only after `main.wait_stream(side)` below has been
-        # enqueued: no record_stream (it would make the caching allocator hold the block until the side
-        # stream drains and cudaMalloc a fresh multi-GB buffer for every pipelined call)
-        buf_s = torch.empty((n_small, 224, 224, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.stream(side):
-            done = 0
-            for lw, k in zip(lws, kepts):
-                done = gather_into(buf_s, done, lw, k, mk_s)
-        forward_range(buf_s, mk_s, 0, n_small - carry)  # full batches; the remainder joins the big level
-    with torch.cuda.stream(side), trace.span(f"window decisions, level {big}"):
-        lwb = LevelWindows(slide, big, stride_of(big))
-        kb = lwb.kept_index()
-        proc_meta[big] = (lwb.meta(kb), int(kb.shape[0]))
-    nb = int(kb.shape[0])
-    if carry + nb:
-        buf_b = torch.empty((carry + nb, 224, 224, 3), dtype=torch.uint8, device=dev)
-        mk_b = []
-        with torch.cuda.stream(side):
-            if carry:
-                buf_b[:carry].copy_(buf_s[n_small - carry:])
-                ev = torch.cuda.Event()
-                ev.record(side)
-                mk_b.append((carry, ev))
-            gather_into(buf_b, carry, lwb, kb, mk_b)
-        forward_range(buf_b, mk_b, 0, carry + nb)
-    main.wait_stream(side)
-    n_total = n_small + nb
+    with trace.span("window decisions, all levels"):
+        lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in levels]
+        # the host's one wait: the kept counts of all levels in one small copy (the index lists themselves follow at once)
+        counts = torch.stack([lw.keep.sum(dtype=torch.int64) for lw in lws]).cpu().tolist() if lws else []
+    n_total = int(sum(counts))
     if n_total == 0:
         return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
-    feats_p = torch.cat([c[0] for c in out_chunks])
-    logits_p = torch.cat([c[1] for c in out_chunks]) if has_fc else None
-    preds_p = torch.cat([c[2] for c in out_chunks]) if has_fc else None
-    # processing order = small levels (as listed), then the big one -> level-major order of `levels`
-    starts, o = {}, 0
-    for lv in small + [big]:
-        starts[lv] = o
-        o += proc_meta[lv][1]
-    perm = torch.cat([torch.arange(starts[lv], starts[lv] + proc_meta[lv][1], device=dev) for lv in levels])
-    metas = torch.cat([proc_meta[lv][0] for lv in levels])
-    return (feats_p.index_select(0, perm), logits_p.index_select(0, perm) if has_fc else None,
-            preds_p.index_select(0, perm) if has_fc else None, metas)
+    kepts = [lw.kept_index() for lw in lws]
+    metas = torch.cat([lw.meta(k) for lw, k in zip(lws, kepts)])
+    buf = net.batch_buffer(n_total, dev)
+    with trace.span("gather kept windows"):
+        done = 0
+        for lw, k in zip(lws, kepts):
+            for i0 in range(0, k.shape[0], max(1, int(batch_windows))):
+                idx = k[i0:i0 + batch_windows]
+                lw.patches(idx, out=buf[done:done + idx.shape[0]])
+                done += idx.shape[0]
+    del lws  # the resampled planes (GBs at level 0) go back to the allocator before the forwards allocate
+    out_chunks = []
+    for lo in range(0, n_total, FWD):
+        end = min(n_total, lo + FWD)
+        with trace.span(f"resnet18 forward [{lo}:{end})"):
+            out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
+    one = len(out_chunks) == 1
+    feats = out_chunks[0][0] if one else torch.cat([c[0] for c in out_chunks])
+    logits = (out_chunks[0][1] if one else torch.cat([c[1] for c in out_chunks])) if has_fc else None
+    preds = (out_chunks[0][2] if one else torch.cat([c[2] for c in out_chunks])) if has_fc else None
+    return feats, logits, preds, metas
 
 
 def save_patch_pngs(slide: DeviceSlide, level: int, out_dir: str, stride: Optional[int] = None) -> int:
