@@ -406,8 +406,10 @@ def run_resnet(args, rank, world, dev):
 
         from ss25_hierarchical_multiscale_image_classification_amd import train_native
         try:
-            sargs = _ap.Namespace(simclr_views=256, warmup=1, steps=3)
-            rec["simclr"] = train_native.bench_simclr_step(sargs, rank, world, dev)
+            sargs = _ap.Namespace(simclr_views=256, warmup=1, steps=3, train_precision="fp32")
+            rec["simclr"] = train_native.bench_simclr_step(sargs, rank, world, dev)  # the reference's arithmetic for this loop
+            sargs.train_precision = "fp16"  # mixed precision (the reference's autocast arithmetic of the fine-tune loops)
+            rec["simclr"]["mixed_precision"] = train_native.bench_simclr_step(sargs, rank, world, dev)
         except (RuntimeError, capi.HipacError) as e:
             rec["simclr"] = {"error": str(e)[:300]}
         torch.cuda.empty_cache()
@@ -531,6 +533,8 @@ def build_parser():
     ap.add_argument("--grid", choices=["reference", "nonoverlap"], default="reference")
     ap.add_argument("--batch_windows", type=int, default=4096)
     ap.add_argument("--simclr_views", type=int, default=1024, help="simclr: images per view per step, over all ranks")
+    ap.add_argument("--train_precision", choices=["fp32", "fp16"], default="fp32",
+                    help="simclr workload: fp32 (the reference's loop) or fp16 mixed precision (autocast-style)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--one_device", action="store_true",

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define HIPAC_ABI_VERSION 3  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3 */
+#define HIPAC_ABI_VERSION 4  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3; 4: hipac_train_amp_* */
 
 /* error codes (positive small values are hipError_t) */
 #define HIPAC_EINVAL (-1)     /* bad argument (shape, enum, null pointer, alignment) */
@@ -322,6 +322,22 @@ int hipac_train_encoder_forward(const float* params, float* stats, const float* 
  * overwritten (accumulate = 0) or added to (accumulate = 1: second view of a SimCLR step). */
 int hipac_train_encoder_backward(const float* params, const float* dfeats, int batch, float* grads, int accumulate,
                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Mixed-precision form of the two calls above -- what the reference's fine-tune loops run under
+ * torch.cuda.amp.autocast() + GradScaler (src/main.py:499-508, :578-587): fp16 operands on the fp16 MFMA with fp32
+ * accumulation, fp16 activations and activation gradients, the SAME fp32 flat parameter / gradient / statistics
+ * buffers.  `x`, `feats`, `dfeats`, `grads` stay float32; `dfeats` arrives multiplied by the caller's loss scale and
+ * `grads` leaves multiplied by it (hipac_grads_unscale_check divides it out and reports inf / nan, as
+ * GradScaler.unscale_ does).  Every reduction is two-stage in a fixed order: the same step run twice gives the same
+ * bits.  batch <= 2048.  Its own workspace size; the maps inside are fp16 NHWC (hipac_train_amp_debug_offset). */
+size_t hipac_train_amp_workspace_bytes(int batch);
+int64_t hipac_train_amp_debug_offset(int batch, int kind, int conv);
+int hipac_train_amp_encoder_forward(const float* params, float* stats, const float* x, int batch, float momentum,
+                                    float eps, float* feats, void* workspace, size_t workspace_bytes, void* stream);
+int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, int batch, float* grads, int accumulate,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+/* grads[i] *= inv_scale; found_inf[0] (device int32, zeroed by the caller) becomes 1 when a gradient is inf / nan. */
+int hipac_grads_unscale_check(float* grads, int64_t n, float inv_scale, int32_t* found_inf, void* stream);
 
 /* nn.Linear forward y = x w^T + b (optional ReLU): projector src/models/simclr.py:20-24, fc resnet.py:66. */
 int hipac_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,

@@ -73,6 +73,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=None, help="seed of the host-side random draws (dataset shuffles, model init); "
                                                        "with --world_size > 1 every rank uses the same one (default 0 there)")
     p.add_argument("--max_steps", type=int, default=None, help="bound the training loops (tests)")
+    p.add_argument("--train_precision", choices=["fp16", "fp32"], default="fp16",
+                   help="arithmetic of the classifier training step: fp16 = the reference's autocast + GradScaler "
+                        "(src/main.py:499-508), fp32 = exact f32 MFMA")
+    p.add_argument("--simclr_precision", choices=["fp16", "fp32"], default="fp32",
+                   help="arithmetic of the SimCLR pre-training step (the reference's loop is fp32, src/models/simclr.py:85-96)")
     p.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
     return p
 
@@ -222,7 +227,8 @@ def cmd_train(args, strategy: Optional[str]):
         print("[ERROR] Patches must be extracted before training.")
         return 1
     train_resnet_classifier(patch_dir, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size,
-                            precision=args.precision, simclr_epochs=args.simclr_epochs, max_steps=args.max_steps)
+                            precision=args.precision, simclr_epochs=args.simclr_epochs, max_steps=args.max_steps,
+                            train_precision=args.train_precision, simclr_precision=args.simclr_precision)
     return 0
 
 

@@ -91,7 +91,7 @@ def get_simclr_transform():
 
 def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr: float = 1e-3, device: str = "cuda",
                     num_workers: int = 8, out_dir: str = ".", max_steps: Optional[int] = None, verbose: bool = True,
-                    final_path: Optional[str] = None):
+                    final_path: Optional[str] = None, precision: str = "fp32"):
     """src/models/simclr.py:68-124 with the step on the native kernels: PatchDataset(transform=None) ->
     SimCLRDataset(two augmented views) -> DataLoader(batch_size, shuffle) -> per batch
     ``z_i = model(x_i); z_j = model(x_j); loss = nt_xent_loss(z_i, z_j); backward; Adam(lr).step()``.
@@ -119,7 +119,7 @@ def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr
         loader = DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=num_workers)
     dev = torch.device(device)
     model = SimCLRModel()
-    trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=lr)
+    trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=lr, precision=precision)  # fp32 = the reference's loop (:85-96)
     trainer.sync_from_rank0()
     verbose = verbose and rank == 0
 

@@ -81,11 +81,13 @@ def class_weights(train_ds: PatchDataset, strategy: Optional[str]) -> Optional[t
 def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epochs: Optional[int] = None,
                             batch_size: int = 512, precision: str = "bf16", lr: float = 1e-4,
                             save_path: Optional[str] = None, device: str = "cuda", simclr_epochs: int = 200,
-                            simclr_path: str = "simclr_encoder.pth", max_steps: Optional[int] = None):
+                            simclr_path: str = "simclr_encoder.pth", max_steps: Optional[int] = None,
+                            train_precision: str = "fp16", simclr_precision: str = "fp32"):
     """``train_resnet_classifier`` (strategy None, 30 epochs, src/main.py:472-534) and
     ``train_resnet_classifier_strategic`` (5 epochs, :536-606).  The training step runs on the native kernels
-    (``train_native.NativeClassifierTrainer``: fp32 -- the reference's fp16 autocast + GradScaler is not imitated);
-    validation scores with the HIP inference path in ``precision``.  ``self_supervised``: pre-trains SimCLR when
+    (``train_native.NativeClassifierTrainer``) in ``train_precision``: "fp16" (default) = the reference's
+    ``autocast()`` + ``GradScaler`` arithmetic (:499-508, :578-587: fp16 operands, fp32 accumulation and master weights,
+    dynamic loss scale), "fp32" = the exact f32 MFMA; validation scores with the HIP inference path in ``precision``.  ``self_supervised``: pre-trains SimCLR when
     ``simclr_path`` does not exist (:556-557), then starts the classifier from that encoder -- what the reference
     means to do (its constructor call raises a TypeError there)."""
     from .dist import all_reduce_sum_scalars, rank_world
@@ -104,7 +106,8 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
 
             # the final checkpoint goes to simclr_path itself, whatever its basename
             pretrain_simclr(patch_dir, epochs=simclr_epochs, batch_size=batch_size, device=device,
-                            out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps, final_path=simclr_path)
+                            out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps, final_path=simclr_path,
+                            precision=simclr_precision)
             if world > 1:
                 torch.distributed.barrier()  # rank 0 wrote the file
         if not os.path.exists(simclr_path):
@@ -116,7 +119,7 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
                 sd["model." + k] = v
         model.load_state_dict(sd)
     w = class_weights(train_ds, strategy)
-    trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w)
+    trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w, precision=train_precision)
     trainer.sync_from_rank0()
     history, steps = [], 0
     for epoch in range(epochs):

@@ -12,9 +12,10 @@ C-ABI calls on flat device buffers --
     gradient all-reduce (N > 1, RCCL)                              torch.distributed (plumbing)
     Adam                                                          hipac_adam_step
 
-PyTorch owns the device memory, the streams and the process group.  Arithmetic is fp32 on the exact f32
-MFMA: the reference's ``pretrain_simclr`` is fp32 as well; its classifier loops run fp16 autocast with a
-GradScaler, which this path does not imitate (fp32 is the more accurate of the two).
+PyTorch owns the device memory, the streams and the process group.  Two arithmetics: "fp32" on the exact f32
+MFMA (the reference's ``pretrain_simclr`` is fp32) and "fp16" mixed precision (csrc/train_amp.hip: fp16 operands and
+maps on the fp16 MFMA, fp32 accumulation and master weights, ``GradScaler``) -- what the reference's classifier loops
+run under ``torch.cuda.amp.autocast()`` (src/main.py:499-508); the classifier trainer defaults to it.
 """
 from __future__ import annotations
 
@@ -64,6 +65,7 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
 
     def step(self):
+        """One Adam update from ``grads`` (callers under a GradScaler unscale and check them first)."""
         self.t += 1
         with torch.cuda.device(self.params.device):
             capi._check(capi.load_library().hipac_adam_step(
@@ -71,13 +73,76 @@ class FlatAdam:
                 self.lr, self.betas[0], self.betas[1], self.eps, self.t, capi._stream()), "hipac_adam_step")
 
 
-class NativeEncoder:
-    """ResNet18 encoder (fc = Identity) as flat device buffers + the native train-mode forward / backward."""
+class GradScaler:
+    """torch.cuda.amp.GradScaler as the reference's fine-tune loops use it (src/main.py:494, :506-508; defaults:
+    init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000): the loss gradient is multiplied by
+    ``scale`` before the fp16 backward, ``unscale_and_check`` divides the fp32 gradients by it and tells whether one of
+    them is inf / nan -- then the optimizer step is skipped and the scale halves; after ``growth_interval`` good steps in
+    a row it doubles.  With several ranks the verdict is shared (MAX), as every replica must skip or step together."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-3):
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), growth_factor, backoff_factor
+        self.growth_interval, self.enabled, self._good = growth_interval, enabled, 0
+        self._flag: Optional[torch.Tensor] = None
+        self.skipped = 0
+
+    def get_scale(self) -> float:
+        return self.scale if self.enabled else 1.0
+
+    def unscale_and_check(self, *flats: "FlatAdam") -> bool:
+        """Divide the loss scale out of every buffer's gradients; True when all of them are finite."""
+        if not self.enabled:
+            return True
+        dev = flats[0].grads.device
+        if self._flag is None or self._flag.device != dev:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._flag.zero_()
+        lib = capi.load_library()
+        with torch.cuda.device(dev):
+            for f in flats:
+                capi._check(lib.hipac_grads_unscale_check(f.grads.data_ptr(), f.grads.numel(), 1.0 / self.scale,
+                                                          self._flag.data_ptr(), capi._stream()), "hipac_grads_unscale_check")
+        bad = float(self._flag.item())
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([bad], dtype=torch.float32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad = float(t.item())
+        return bad == 0.0
+
+    def update(self, ok: bool):
+        if not self.enabled:
+            return
+        if ok:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+        else:
+            self.scale *= self.backoff_factor
+            self._good = 0
+            self.skipped += 1
+
+
+class NativeEncoder:
+    """ResNet18 encoder (fc = Identity) as flat device buffers + the native train-mode forward / backward.
+    ``precision``: "fp32" (exact f32 MFMA: the reference's pretrain_simclr arithmetic) or "fp16" (mixed precision: fp16
+    operands and maps on the fp16 MFMA, fp32 accumulation, the same fp32 flat buffers -- the reference's autocast loops)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-3, precision: str = "fp32"):
         """``sd``: bare torchvision-named tensors (``weights.canonical_state_dict`` of any reference layout)."""
+        if precision not in ("fp32", "fp16"):
+            raise capi.HipacError("training precision must be 'fp32' or 'fp16'")
+        self.precision = precision
         self.device = torch.device(device)
         self.lib = capi.load_library()
+        amp = precision == "fp16"
+        self._fn_ws = self.lib.hipac_train_amp_workspace_bytes if amp else self.lib.hipac_train_workspace_bytes
+        self._fn_fwd = self.lib.hipac_train_amp_encoder_forward if amp else self.lib.hipac_train_encoder_forward
+        self._fn_bwd = self.lib.hipac_train_amp_encoder_backward if amp else self.lib.hipac_train_encoder_backward
+        self._fn_off = self.lib.hipac_train_amp_debug_offset if amp else self.lib.hipac_train_debug_offset
+        self._map_dtype, self._map_bytes = (torch.float16, 2) if amp else (torch.float32, 4)
         self.table = conv_table()
         self.opt = FlatAdam(self.lib.hipac_train_param_floats(), self.device, lr)
         self.stats = torch.zeros(self.lib.hipac_train_stat_floats(), dtype=torch.float32, device=self.device)
@@ -123,7 +188,7 @@ class NativeEncoder:
 
     # ---- compute -----------------------------------------------------------------------------
     def workspace(self, slot: int, batch: int) -> torch.Tensor:
-        need = self.lib.hipac_train_workspace_bytes(batch)
+        need = self._fn_ws(batch)
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -139,7 +204,7 @@ class NativeEncoder:
         ws = self.workspace(slot, B)
         feats = torch.empty((B, 512), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            capi._check(self.lib.hipac_train_encoder_forward(
+            capi._check(self._fn_fwd(
                 self.opt.params.data_ptr(), self.stats.data_ptr() if update_stats else None, x.data_ptr(), B, BN_MOMENTUM, BN_EPS,
                 feats.data_ptr(), ws.data_ptr(), ws.numel(), capi._stream()), "hipac_train_encoder_forward")
         if update_stats:
@@ -150,7 +215,7 @@ class NativeEncoder:
         """Test tap: a map the last forward left in workspace ``slot`` -- kind "pre" / "post" -> float32 NCHW
         [B,Cout,H,W] of conv ``conv``, "pool" -> the pooled stem map, "stats" -> (mean, rstd)."""
         B, e = self._ws_batch[slot], self.table[conv]
-        off = self.lib.hipac_train_debug_offset(B, {"pre": 0, "post": 1, "pool": 2, "stats": 3, "pool_idx": 4}[kind], conv)
+        off = self._fn_off(B, {"pre": 0, "post": 1, "pool": 2, "stats": 3, "pool_idx": 4}[kind], conv)
         if off < 0:
             raise capi.HipacError("train tap: bad argument")
         if kind == "pool_idx":  # uint8 NCHW [B,64,56,56]: which of the 9 window positions (dy * 3 + dx) won
@@ -165,7 +230,8 @@ class NativeEncoder:
             C_ = e["cout"]
             H = {0: 112}.get(conv, {64: 56, 128: 28, 256: 14, 512: 7}[C_])
         n = B * H * H * C_
-        return self._ws[slot][off:off + 4 * n].view(torch.float32).view(B, H, H, C_).permute(0, 3, 1, 2).contiguous()
+        return (self._ws[slot][off:off + self._map_bytes * n].view(self._map_dtype).view(B, H, H, C_).permute(0, 3, 1, 2)
+                .contiguous().float())
 
     def backward(self, dfeats: torch.Tensor, slot: int = 0, accumulate: bool = False):
         B = self._ws_batch[slot]
@@ -173,7 +239,7 @@ class NativeEncoder:
             raise capi.HipacError("dfeats must be a contiguous float32[B,512] tensor of the forward's batch")
         ws = self._ws[slot]
         with torch.cuda.device(self.device):
-            capi._check(self.lib.hipac_train_encoder_backward(
+            capi._check(self._fn_bwd(
                 self.opt.params.data_ptr(), dfeats.data_ptr(), B, self.opt.grads.data_ptr(), 1 if accumulate else 0,
                 ws.data_ptr(), ws.numel(), capi._stream()), "hipac_train_encoder_backward")
 
@@ -237,13 +303,16 @@ def _all_gather_rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
 class NativeSimCLRTrainer:
     """SimCLRModel (src/models/simclr.py:14-29) + nt_xent_loss (:31-54) + Adam(lr) (:79), one native step per call."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-3, temperature: float = 0.5, out_dim: int = 128):
-        """``sd``: a SimCLRModel state_dict (``encoder.*``, ``projector.{0,2}.*``)."""
+    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-3, temperature: float = 0.5, out_dim: int = 128,
+                 precision: str = "fp32", scaler: Optional[GradScaler] = None):
+        """``sd``: a SimCLRModel state_dict (``encoder.*``, ``projector.{0,2}.*``).  ``precision``: "fp32" (the
+        reference's arithmetic for this loop, src/models/simclr.py:85-96) or "fp16" (opt-in mixed precision with a GradScaler)."""
         from .weights import canonical_state_dict
 
         self.device = torch.device(device)
         bare = canonical_state_dict({k: v for k, v in sd.items() if not k.startswith("projector.")})
-        self.encoder = NativeEncoder(bare, self.device, lr)
+        self.encoder = NativeEncoder(bare, self.device, lr, precision=precision)
+        self.scaler = scaler if scaler is not None else GradScaler(enabled=precision == "fp16")
         n1, n2 = NativeLinear.floats(512, 512), NativeLinear.floats(out_dim, 512)
         self.head = FlatAdam(n1 + n2, self.device, lr)
         self.p1 = NativeLinear(self.head, 0, 512, 512, relu=True)
@@ -265,6 +334,8 @@ class NativeSimCLRTrainer:
         Zj, _ = _all_gather_rows(z_j)
         loss, dZ = capi.ntxent_fwd_bwd(torch.cat([Zi, Zj], dim=0), self.temperature, want_grad=True)
         n, N = z_i.shape[0], Zi.shape[0]
+        if self.scaler.enabled:
+            dZ = dZ * self.scaler.get_scale()  # the loss scale rides on every gradient until unscale_and_check
         dz_i, dz_j = dZ[r0:r0 + n].contiguous(), dZ[N + r0:N + r0 + n].contiguous()
         dh_i = self.p2.backward(h_i, z_i, dz_i, accumulate=False)
         dh_j = self.p2.backward(h_j, z_j, dz_j, accumulate=True)
@@ -286,8 +357,11 @@ class NativeSimCLRTrainer:
 
     def step(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
         loss = self.forward_backward(x_i, x_j)
-        self.encoder.opt.step()
-        self.head.step()
+        ok = self.scaler.unscale_and_check(self.encoder.opt, self.head)  # fp32: nothing to do, always True
+        if ok:
+            self.encoder.opt.step()
+            self.head.step()
+        self.scaler.update(ok)
         return loss
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -306,13 +380,17 @@ class NativeSimCLRTrainer:
 class NativeClassifierTrainer:
     """ResNet18Classifier (src/models/resnet.py:57-77) + CrossEntropyLoss(weight) + Adam(1e-4) (src/main.py:485-492)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-4, class_weights: Optional[torch.Tensor] = None):
-        """``sd``: a ResNet18Classifier state_dict (``model.*`` incl. ``model.fc``), any reference layout."""
+    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", lr: float = 1e-4, class_weights: Optional[torch.Tensor] = None,
+                 precision: str = "fp16", scaler: Optional[GradScaler] = None):
+        """``sd``: a ResNet18Classifier state_dict (``model.*`` incl. ``model.fc``), any reference layout.
+        ``precision``: "fp16" (default: the reference runs this step under autocast + GradScaler, src/main.py:499-508) or
+        "fp32" (exact f32 MFMA, the wider arithmetic)."""
         from .weights import canonical_state_dict
 
         self.device = torch.device(device)
         bare = canonical_state_dict(sd)
-        self.encoder = NativeEncoder(bare, self.device, lr)
+        self.encoder = NativeEncoder(bare, self.device, lr, precision=precision)
+        self.scaler = scaler if scaler is not None else GradScaler(enabled=precision == "fp16")
         C_ = int(bare["fc.weight"].shape[0])
         self.head = FlatAdam(NativeLinear.floats(C_, 512), self.device, lr)
         self.fc = NativeLinear(self.head, 0, C_, 512)
@@ -341,6 +419,8 @@ class NativeClassifierTrainer:
                 L.data_ptr(), Y.data_ptr(), capi._ptr(self.class_weights), L.shape[0], L.shape[1],
                 loss.data_ptr(), dL.data_ptr(), self._scratch.data_ptr(), capi._stream()), "hipac_cross_entropy_fwd_bwd")
         dlogits = dL[r0:r0 + logits.shape[0]].contiguous()
+        if self.scaler.enabled:
+            dlogits = dlogits * self.scaler.get_scale()
         df = self.fc.backward(f, logits, dlogits, accumulate=False)
         self.encoder.backward(df, slot=0, accumulate=False)
         _all_reduce_sum(self.encoder.opt.grads)
@@ -356,8 +436,11 @@ class NativeClassifierTrainer:
 
     def step(self, x: torch.Tensor, labels: torch.Tensor):
         loss, logits = self.forward_backward(x, labels)
-        self.encoder.opt.step()
-        self.head.step()
+        ok = self.scaler.unscale_and_check(self.encoder.opt, self.head)
+        if ok:
+            self.encoder.opt.step()
+            self.head.step()
+        self.scaler.update(ok)
         return loss, logits
 
     def state_dict(self, prefix: str = "model.") -> Dict[str, torch.Tensor]:
@@ -384,7 +467,8 @@ def bench_simclr_step(args, rank: int, world: int, dev) -> dict:
 
     torch.manual_seed(0)
     model = SimCLRModel()
-    trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=1e-3)
+    prec = getattr(args, "train_precision", "fp32")
+    trainer = NativeSimCLRTrainer(model.state_dict(), device=dev, lr=1e-3, precision=prec)
     n = max(1, args.simclr_views // world)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     x_i = torch.randn((n, 3, 224, 224), generator=g, device=dev)
@@ -411,7 +495,7 @@ def bench_simclr_step(args, rank: int, world: int, dev) -> dict:
     rec = {
         "metric": "SimCLR training step, images/s (ResNet18 encoder fwd+bwd, NT-Xent, Adam)", "value": imgs / dt,
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if prec == "fp32" else "f16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
         "config": {"workload": f"simclr_step_2x{n * world}_views", "views_per_rank": n, "projector": "512-512-128",
                    "loss": "NT-Xent T=0.5 over the global batch", "optimizer": "Adam lr 1e-3",
                    "parallelism": f"data parallel x{world}: all-gather of z, all-reduce(sum) of 11.5 M fp32 gradients"
@@ -431,8 +515,12 @@ def bench_simclr_step(args, rank: int, world: int, dev) -> dict:
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 2
         tf = FWD_FLOP_PER_IMAGE * n / (ms * 1e-3) / 1e12
-        rec["roofline"] = {"bound": "mfma", "kernel": "train-mode encoder forward (conv_igemm_kernel<float> + BN passes)",
-                           "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
-                           "launch_ms": ms, "flops_per_launch": FWD_FLOP_PER_IMAGE * n, "images_per_launch": n}
-        rec["frac_of_f32_mfma_peak_whole_step"] = rec["tflops"] / world / 157.3
+        peak = 157.3 if prec == "fp32" else 2500.0
+        kern = ("train-mode encoder forward (conv_igemm_kernel<float> + BN passes)" if prec == "fp32" else
+                "train-mode encoder forward (fp16 halo / LDS-DMA conv kernels + fp16 BN passes)")
+        rec["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                           "traffic": None, "launch_ms": ms, "flops_per_launch": FWD_FLOP_PER_IMAGE * n, "images_per_launch": n}
+        rec["frac_of_mfma_peak_whole_step"] = rec["tflops"] / world / peak
+        if prec == "fp16":
+            rec["loss_scale"], rec["skipped_steps"] = trainer.scaler.get_scale(), trainer.scaler.skipped
     return rec
