@@ -14,6 +14,8 @@
 //             read TRANSPOSED from LDS by ds_read_b64_tr_b16, split-K partials in fp32 summed in a fixed order (no
 //             atomics: a step run twice gives the same bits).
 // The gradients that arrive (dfeats) and leave (grads) carry the caller's loss scale.
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 #include "train_common.h"
 
@@ -165,15 +167,20 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const h16* __restrict_
   }
 }
 
-// partial sums -> sums[c], sums[512 + c] in a fixed order; FINAL: also mean / rstd and the running statistics
+// partial sums -> sums[c], sums[512 + c] in a FIXED order (lane l of the channel's 32 adds blocks l, l + 32, ... in turn,
+// then a shuffle tree): 8 channels per workgroup; FINAL: also mean / rstd and the running statistics
 template <bool FINAL>
-__global__ void bn_sum_parts_kernel(const double* __restrict__ part, int nblocks, int C, double* __restrict__ sums, long long M,
-                                    float eps, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                    float* __restrict__ run_mean, float* __restrict__ run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_sum_parts_kernel(const double* __restrict__ part, int nblocks, int C,
+                                                           double* __restrict__ sums, long long M, float eps, float momentum,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   double a = 0, b = 0;
-  for (int k = 0; k < nblocks; ++k) a += part[(size_t)k * 1024 + c], b += part[(size_t)k * 1024 + 512 + c];
+  if (c < C)
+    for (int k = l; k < nblocks; k += 32) a += part[(size_t)k * 1024 + c], b += part[(size_t)k * 1024 + 512 + c];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) a += __shfl_down(a, o, 32), b += __shfl_down(b, o, 32);
+  if (c >= C || l != 0) return;
   sums[c] = a, sums[512 + c] = b;
   if (FINAL) {
     const double mu = a / (double)M;
@@ -189,17 +196,24 @@ __global__ void bn_sum_parts_kernel(const double* __restrict__ part, int nblocks
   }
 }
 
-// y = (x - mean) * rstd * gamma + beta (+ resid) (ReLU), fp16 -> fp16
+// y = (x - mean) * rstd * gamma + beta (+ resid) (ReLU), fp16 -> fp16.  The grid stride (a multiple of 2048 elements) is a
+// multiple of C, so a thread meets the same 8 channels in every iteration: their constants are loaded once.
 __global__ __launch_bounds__(256) void bn_apply_h_kernel(const h16* __restrict__ x, const h16* __restrict__ resid,
                                                          h16* __restrict__ y, long long n8, int C, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int relu) {
+  const int c = (threadIdx.x * 8) % C;
+  float mu[8], sc[8], be[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mu[k] = mean[c + k], sc[k] = rstd[c + k], be[k] = beta[c + k];
+  float ga[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ga[k] = gamma[c + k];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-    const int c = (int)((i * 8) % C);
     float v[8], o[8];
     ld8(x + i * 8, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (v[k] - mean[c + k]) * rstd[c + k] * gamma[c + k] + beta[c + k];
+    for (int k = 0; k < 8; ++k) o[k] = (v[k] - mu[k]) * sc[k] * ga[k] + be[k];
     if (resid) {
       float r[8];
       ld8(resid + i * 8, r);
@@ -229,8 +243,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const h16* __restri
     }
   }
   const double invM = 1.0 / (double)M;
+  const int c = (threadIdx.x * 8) % C;  // the same 8 channels in every iteration (grid stride is a multiple of C)
+  float mu[8], rs[8], gr[8], sb[8], sg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = mean[c + k], rs[k] = rstd[c + k], gr[k] = gamma[c + k] * rstd[c + k];
+    sb[k] = (float)(sums[c + k] * invM), sg[k] = (float)(sums[512 + c + k] * invM);
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-    const int c = (int)((i * 8) % C);
     float d[8], v[8], o[8];
     ld8(dy + i * 8, d);
     ld8(x + i * 8, v);
@@ -241,11 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const h16* __restri
       for (int k = 0; k < 8; ++k) d[k] = m[k] > 0.f ? d[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (v[k] - mean[c + k]) * rstd[c + k];
-      const float sb = (float)(sums[c + k] * invM), sg = (float)(sums[512 + c + k] * invM);
-      o[k] = gamma[c + k] * rstd[c + k] * (d[k] - sb - xh * sg);
-    }
+    for (int k = 0; k < 8; ++k) o[k] = gr[k] * (d[k] - sb[k] - (v[k] - mu[k]) * rs[k] * sg[k]);
     st8(dx + i * 8, o);
   }
 }
@@ -289,61 +305,81 @@ __global__ __launch_bounds__(256) void upsample_zero_h_kernel(const h16* __restr
   }
 }
 
-// 3x3/2 max-pool, pad 1, with the arg-max kept (first maximum in (dy, dx) scan order, as torch)
+// 3x3/2 max-pool, pad 1, with the arg-max kept (first maximum in (dy, dx) scan order, as torch); 8 channels per thread
 __global__ __launch_bounds__(256) void maxpool_idx_h_kernel(const h16* __restrict__ in, h16* __restrict__ out,
-                                                            unsigned char* __restrict__ idx, long long total) {
+                                                            unsigned char* __restrict__ idx, long long total8) {
   constexpr int HI = 112, HO = 56, C = 64;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int c = (int)(gid % C);
-  long long p = gid / C;
+  if (gid >= total8) return;
+  const int c8 = (int)(gid % (C / 8));
+  long long p = gid / (C / 8);
   const int ow = (int)(p % HO);
   p /= HO;
   const int oh = (int)(p % HO);
   const long long b = p / HO;
-  float best = -INFINITY;
-  int bi = 9;
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) best[k] = -INFINITY, bi[k] = 9;
+#pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
     const int ih = oh * 2 - 1 + dy;
     if ((unsigned)ih >= (unsigned)HI) continue;
+#pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int iw = ow * 2 - 1 + dx;
       if ((unsigned)iw >= (unsigned)HI) continue;
-      const float v = (float)in[((b * HI + ih) * HI + iw) * C + c];
-      if (v > best || bi == 9) best = v, bi = dy * 3 + dx;
+      float v[8];
+      ld8(in + ((b * HI + ih) * HI + iw) * C + 8 * c8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (v[k] > best[k] || bi[k] == 9) best[k] = v[k], bi[k] = dy * 3 + dx;
     }
   }
-  out[gid] = (h16)best;
-  idx[gid] = (unsigned char)bi;
+  st8(out + gid * 8, best);
+  unsigned lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lo |= (unsigned)bi[k] << (8 * k), hi |= (unsigned)bi[4 + k] << (8 * k);
+  *reinterpret_cast<u32x2*>(idx + gid * 8) = u32x2{lo, hi};
 }
 
+// max-pool backward (gather form): every input position sums the gradients of the <= 4 windows that chose it
 __global__ __launch_bounds__(256) void maxpool_bwd_h_kernel(const h16* __restrict__ dout, const unsigned char* __restrict__ idx,
-                                                            h16* __restrict__ din, long long total) {
+                                                            h16* __restrict__ din, long long total8) {
   constexpr int HI = 112, HO = 56, C = 64;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int c = (int)(gid % C);
-  long long p = gid / C;
+  if (gid >= total8) return;
+  const int c8 = (int)(gid % (C / 8));
+  long long p = gid / (C / 8);
   const int iw = (int)(p % HI);
   p /= HI;
   const int ih = (int)(p % HI);
   const long long b = p / HI;
-  float acc = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
     const int t = ih + 1 - dy;
     if (t < 0 || (t & 1)) continue;
     const int oh = t >> 1;
     if (oh >= HO) continue;
+#pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int u = iw + 1 - dx;
       if (u < 0 || (u & 1)) continue;
       const int ow = u >> 1;
       if (ow >= HO) continue;
-      const long long o = ((b * HO + oh) * HO + ow) * C + c;
-      if (idx[o] == dy * 3 + dx) acc += (float)dout[o];
+      const long long o = ((b * HO + oh) * HO + ow) * C + 8 * c8;
+      const u32x2 ib = *reinterpret_cast<const u32x2*>(idx + o);
+      float g[8];
+      ld8(dout + o, g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((int)(((k < 4 ? ib[0] : ib[1]) >> (8 * (k & 3))) & 0xffu) == dy * 3 + dx) acc[k] += g[k];
     }
   }
-  din[gid] = (h16)acc;
+  st8(din + gid * 8, acc);
 }
 
 __global__ __launch_bounds__(256) void avgpool_h_kernel(const h16* __restrict__ last, float* __restrict__ feats, int n) {
@@ -368,24 +404,28 @@ __global__ __launch_bounds__(256) void avgpool_bwd_h_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // weight gradient on the fp16 MFMA:  part[slice][tap][co][ci] = sum over the slice's output pixels m of
 //     dY[m][co] * X[pixel(m, tap)][ci]
-// One workgroup = one (TC x TC) (co x ci) tile of one filter tap over one slice of the pixel axis; 4 waves = 2 x 2
-// wave tiles of (TC/2)^2.  The contraction runs over PIXELS, but both operands lie [pixel][channel] in memory: they
-// are staged as they come (16-byte pieces, rows of TC channels) and the MFMA fragments -- 8 consecutive pixels of one
-// channel -- are read TRANSPOSED with ds_read_b64_tr_b16 (two per fragment).  LDS row pitch = 2 TC + 64 bytes: the 4
-// rows x 2 channel blocks of a 32-lane half then fall on 64 distinct banks.  Sub-chunks of 32 pixels, double-buffered
-// through registers (the next sub-chunk's global loads are in flight behind the MFMAs), one barrier per sub-chunk.
-// STEM: X is the padded NHWC4 input, the "ci" axis of a tile is the 32 values (kw, c) of filter row kh (TC = 64: only the
-// first 32 columns of the tile exist).
+// One workgroup = one (TC x TC) (co x ci) tile of NTAP filter taps over one slice of the pixel axis; 4 waves = 2 x 2
+// wave tiles of (TC/2)^2 per tap.  The dY tile is staged ONCE per 32-pixel sub-chunk and multiplied with the NTAP
+// shifted X tiles (one filter row = 3 taps for the 64-channel layers, 7 filter rows for the stem, 1 tap for the wide
+// layers, whose 128 x 128 tiles are bound by the operand streams, not by the staging): NTAP MFMAs per dY fragment.  The contraction runs over PIXELS, but both operands lie
+// [pixel][channel] in memory: they are staged as they come (16-byte pieces, rows of TC channels) and the MFMA
+// fragments -- 8 consecutive pixels of one channel -- are read TRANSPOSED with ds_read_b64_tr_b16 (two per fragment).
+// LDS row pitch = 2 TC + 64 bytes: the 4 rows x 2 channel blocks of a 32-lane half then fall on 64 distinct banks.
+// The next sub-chunk's global loads are in flight behind the MFMAs; two barriers per sub-chunk.
+// STEM: X is the padded NHWC4 input, a "tap" is filter row kh and the "ci" axis of its tile the 32 values (kw, c)
+// (TC = 64: only the first 32 columns exist, waves wj = 1 take the odd filter rows instead of a second column half).
 // ---------------------------------------------------------------------------------------------
-template <int TC, bool STEM>
+template <int TC, int NTAP, bool STEM>
 __global__ __launch_bounds__(256) void wgrad_f16_kernel(const h16* __restrict__ dY, const h16* __restrict__ X,
                                                         float* __restrict__ part, int Cout, int Cin, int KS, int stride, int HO,
                                                         int HI, long long M, int chunk) {
   constexpr int PITCH = 2 * TC + 64;             // bytes per staged pixel row
   constexpr int CH = TC / 8;                     // 16-byte pieces per row
-  constexpr int PPT = 32 * CH / 256;             // pieces per thread and operand (1 for TC = 64, 2 for TC = 128)
+  constexpr int PPT = 32 * CH / 256;             // pieces per thread and tile (1 for TC = 64, 2 for TC = 128)
   constexpr int WT = TC / 2, NF = WT / 32;       // wave tile, 32-wide fragments per wave and operand
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 32 * PITCH];
+  constexpr int TILE = 32 * PITCH;
+  constexpr int MYT = STEM ? (NTAP + 1) / 2 : NTAP;  // taps a wave accumulates
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(1 + NTAP) * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int ci_tiles = STEM ? 1 : Cin / TC, co_tiles = Cout / TC;
@@ -393,44 +433,51 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(const h16* __restrict__ 
   const int cit = t % ci_tiles;
   t /= ci_tiles;
   const int cot = t % co_tiles;
-  const int tap = t / co_tiles;
-  const int kh = STEM ? tap : tap / KS, kw = STEM ? 0 : tap % KS;
+  const int tap0 = (t / co_tiles) * NTAP;
   const int pad = STEM ? 0 : KS / 2;
-  const int wi = wave & 1, wj = wave >> 1;  // co half, ci half
-  f32x16 acc[NF][NF];
+  const int wi = wave & 1, wj = wave >> 1;  // co half, ci half (STEM: filter-row parity)
+  f32x16 acc[MYT][NF][NF];
 #pragma unroll
-  for (int i = 0; i < NF; ++i)
+  for (int tp = 0; tp < MYT; ++tp)
 #pragma unroll
-    for (int j = 0; j < NF; ++j)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tp][i][j][e] = 0.f;
   const long long m_begin = (long long)blockIdx.y * chunk;
   const long long m_end = m_begin + chunk < M ? m_begin + chunk : M;
 
-  u32x4 ra[PPT], rb[PPT];
+  u32x4 ra[PPT], rb[NTAP][PPT];
   auto gload = [&](long long m0) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const int piece = tid + 256 * k, spx = piece / CH, sc = piece % CH;
       const long long m = m0 + spx;
-      ra[k] = rb[k] = u32x4{0u, 0u, 0u, 0u};
+      ra[k] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int tp = 0; tp < NTAP; ++tp) rb[tp][k] = u32x4{0u, 0u, 0u, 0u};
       if (m < m_end) {
         ra[k] = *reinterpret_cast<const u32x4*>(dY + m * Cout + cot * TC + 8 * sc);
         const int ox = (int)(m % HO);
         const long long tt = m / HO;
         const int oy = (int)(tt % HO);
         const long long b = tt / HO;
-        if constexpr (STEM) {
-          if (sc < 4) rb[k] = *reinterpret_cast<const u32x4*>(X + (((b * kPadH + 2 * oy + kh) * kPadW) + 2 * ox) * 4 + 8 * sc);
-        } else {
-          const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-          if ((unsigned)iy < (unsigned)HI && (unsigned)ix < (unsigned)HI)
-            rb[k] = *reinterpret_cast<const u32x4*>(X + ((b * HI + iy) * HI + ix) * (long long)Cin + cit * TC + 8 * sc);
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp) {
+          if constexpr (STEM) {
+            if (sc < 4) rb[tp][k] = *reinterpret_cast<const u32x4*>(X + (((b * kPadH + 2 * oy + tap0 + tp) * kPadW) + 2 * ox) * 4 + 8 * sc);
+          } else {
+            const int tap = tap0 + tp, kh = tap / KS, kw = tap - kh * KS;
+            const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+            if ((unsigned)iy < (unsigned)HI && (unsigned)ix < (unsigned)HI)
+              rb[tp][k] = *reinterpret_cast<const u32x4*>(X + ((b * HI + iy) * HI + ix) * (long long)Cin + cit * TC + 8 * sc);
+          }
         }
       }
     }
   };
-  // transposed fragment address of this lane inside an operand image: block row q = (lane & 15) >> 2, column quad p = lane & 3
+  // transposed fragment address of this lane inside a tile: block row q = (lane & 15) >> 2, column quad p = lane & 3
   const int tr_off = ((lane & 15) >> 2) * PITCH + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2 + 8 * h * PITCH;
   auto frag_tr = [&](const unsigned char* img, int col0, int kk) -> f16x8 {
     const unsigned char* p = img + tr_off + (16 * kk) * PITCH + col0 * 2;
@@ -440,65 +487,85 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(const h16* __restrict__ 
   };
 
   gload(m_begin);
-  int buf = 0;
-  for (long long m0 = m_begin; m0 < m_end; m0 += 32, buf ^= 1) {
-    unsigned char* As = smem + buf * (2 * 32 * PITCH);
-    unsigned char* Bs = As + 32 * PITCH;
+  for (long long m0 = m_begin; m0 < m_end; m0 += 32) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const int piece = tid + 256 * k, spx = piece / CH, sc = piece % CH;
-      *reinterpret_cast<u32x4*>(As + spx * PITCH + 16 * sc) = ra[k];
-      *reinterpret_cast<u32x4*>(Bs + spx * PITCH + 16 * sc) = rb[k];
+      *reinterpret_cast<u32x4*>(smem + spx * PITCH + 16 * sc) = ra[k];
+#pragma unroll
+      for (int tp = 0; tp < NTAP; ++tp) *reinterpret_cast<u32x4*>(smem + (1 + tp) * TILE + spx * PITCH + 16 * sc) = rb[tp][k];
     }
-    __syncthreads();  // this buffer is complete; the other one was read two sub-chunks ago by every wave
-    if (m0 + 32 < m_end) gload(m0 + 32);
+    __syncthreads();
+    if (m0 + 32 < m_end) gload(m0 + 32);  // in flight behind the MFMAs (and the other workgroups of the CU)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      f16x8 af[NF], bf[NF];
+      f16x8 af[NF];
 #pragma unroll
-      for (int i = 0; i < NF; ++i) af[i] = frag_tr(As, wi * WT + 32 * i, kk);
+      for (int i = 0; i < NF; ++i) af[i] = frag_tr(smem, wi * WT + 32 * i, kk);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) bf[j] = frag_tr(Bs, wj * WT + 32 * j, kk);
+      for (int tp = 0; tp < MYT; ++tp) {
+        const int tile = STEM ? 2 * tp + wj : tp;
+        if (STEM && tile >= NTAP) continue;
+        f16x8 bf[NF];
 #pragma unroll
-      for (int i = 0; i < NF; ++i)
+        for (int j = 0; j < NF; ++j) bf[j] = frag_tr(smem + (1 + tile) * TILE, (STEM ? 0 : wj * WT) + 32 * j, kk);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j) acc[tp][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[tp][i][j], 0, 0, 0);
+      }
     }
+    __syncthreads();  // every wave has read the tiles: the next sub-chunk may overwrite them
   }
   // D[co][ci]: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h
   const int row_len = STEM ? 32 : Cin;
   const int ntaps = STEM ? 7 : KS * KS;
-  float* base = part + ((size_t)blockIdx.y * ntaps + tap) * (size_t)Cout * row_len;
 #pragma unroll
-  for (int i = 0; i < NF; ++i)
+  for (int tp = 0; tp < MYT; ++tp) {
+    const int tap = tap0 + (STEM ? 2 * tp + wj : tp);
+    if (STEM && tap >= NTAP) continue;
+    float* base = part + ((size_t)blockIdx.y * ntaps + tap) * (size_t)Cout * row_len;
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      const int col = (STEM ? 0 : cit * TC) + wj * WT + 32 * j + r;
-      if (STEM && col >= 32) continue;
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = cot * TC + wi * WT + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        base[(size_t)row * row_len + col] = acc[i][j][e];
+      for (int j = 0; j < NF; ++j) {
+        const int col = (STEM ? 0 : cit * TC + wj * WT) + 32 * j + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = cot * TC + wi * WT + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          base[(size_t)row * row_len + col] = acc[tp][i][j][e];
+        }
       }
-    }
+  }
 }
 
-// split-K partials -> the PyTorch-layout gradient (accumulate or overwrite), slices summed in order
+// split-K partials -> the PyTorch-layout gradient (accumulate or overwrite).  32 weights per workgroup x 8 slice groups:
+// group g adds slices g, g + 8, ... in turn, then the 8 group sums are added in order -- a fixed order, hence deterministic
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slices, float* __restrict__ dw,
                                                            int cout, int cin, int ks, int stem, int accumulate) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long gid = (long long)blockIdx.x * 32 + e;
   const long long total = (long long)cout * cin * ks * ks;
-  if (gid >= total) return;
-  const int kw = (int)(gid % ks);
-  long long t = gid / ks;
-  const int kh = (int)(t % ks);
-  t /= ks;
-  const int ci = (int)(t % cin), co = (int)(t / cin);
-  const size_t per_slice = stem ? (size_t)7 * cout * 32 : (size_t)total;
-  const size_t o = stem ? ((size_t)kh * cout + co) * 32 + kw * 4 + ci : ((size_t)(kh * ks + kw) * cout + co) * cin + ci;
   float s = 0.f;
-  for (int k = 0; k < slices; ++k) s += part[(size_t)k * per_slice + o];
-  dw[gid] = accumulate ? dw[gid] + s : s;
+  if (gid < total) {
+    const int kw = (int)(gid % ks);
+    long long t = gid / ks;
+    const int kh = (int)(t % ks);
+    t /= ks;
+    const int ci = (int)(t % cin), co = (int)(t / cin);
+    const size_t per_slice = stem ? (size_t)7 * cout * 32 : (size_t)total;
+    const size_t o = stem ? ((size_t)kh * cout + co) * 32 + kw * 4 + ci : ((size_t)(kh * ks + kw) * cout + co) * cin + ci;
+    for (int k = g; k < slices; k += 8) s += part[(size_t)k * per_slice + o];
+  }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && gid < total) {
+    float v = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += red[k][e];
+    dw[gid] = accumulate ? dw[gid] + v : v;
+  }
 }
 
 // grads *= inv_scale; flag[0] = 1 when a gradient is not finite (GradScaler.unscale_)
@@ -610,7 +677,7 @@ static int bn_forward_h(const AmpCtx& c, int i, int n, const h16* resid, int rel
   hipLaunchKernelGGL((bn_reduce_h_kernel<0>), dim3(gs), dim3(256), 0, c.s, x, (const h16*)nullptr, (const h16*)nullptr, M, d.cout,
                      (const float*)nullptr, (const float*)nullptr, part);
   float* rm = c.stats ? c.stats + stat_offset(i) : nullptr;
-  hipLaunchKernelGGL((bn_sum_parts_kernel<true>), dim3((d.cout + 255) / 256), dim3(256), 0, c.s, (const double*)part, gs, d.cout,
+  hipLaunchKernelGGL((bn_sum_parts_kernel<true>), dim3((d.cout + 7) / 8), dim3(256), 0, c.s, (const double*)part, gs, d.cout,
                      sums, M, c.eps, c.momentum, mean, rstd, rm, rm ? rm + d.cout : nullptr);
   const long long n8 = M * d.cout / 8;
   hipLaunchKernelGGL(bn_apply_h_kernel, dim3(grid_for(n8)), dim3(256), 0, c.s, x, resid, y, n8, d.cout, (const float*)mean,
@@ -630,7 +697,7 @@ static int bn_backward_h(const AmpCtx& c, int i, int n, const h16* dy, const h16
   float* dgamma = grads + param_offset(i) + conv_w_floats(i);
   const int gs = red_blocks(M, d.cout);
   hipLaunchKernelGGL((bn_reduce_h_kernel<1>), dim3(gs), dim3(256), 0, c.s, dy, x, ymask, M, d.cout, mean, rstd, part);
-  hipLaunchKernelGGL((bn_sum_parts_kernel<false>), dim3((d.cout + 255) / 256), dim3(256), 0, c.s, (const double*)part, gs, d.cout,
+  hipLaunchKernelGGL((bn_sum_parts_kernel<false>), dim3((d.cout + 7) / 8), dim3(256), 0, c.s, (const double*)part, gs, d.cout,
                      sums, M, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   const long long n8 = M * d.cout / 8;
   hipLaunchKernelGGL(bn_bwd_apply_h_kernel, dim3(grid_for(n8)), dim3(256), 0, c.s, dy, x, ymask, dx, n8, M, d.cout, mean, rstd,
@@ -647,9 +714,13 @@ static int conv_wgrad_h(const AmpCtx& c, int i, int n, const h16* X, const h16* 
   const size_t pf = stem ? (size_t)7 * 64 * 32 : conv_w_floats(i);
   const bool big = !stem && d.cout >= 128 && d.cin >= 128;
   const int TC = big ? 128 : 64;
-  const int tiles = stem ? 7 : d.ks * d.ks * (d.cout / TC) * (d.cin / TC);
+  static const int knob_big = getenv("HIPAC_WG_NTAP_BIG") ? atoi(getenv("HIPAC_WG_NTAP_BIG")) : 1;      // developer knobs; measured (2 x 1024 views, img/s):
+  static const int knob_small = getenv("HIPAC_WG_NTAP_SMALL") ? atoi(getenv("HIPAC_WG_NTAP_SMALL")) : 3;  // (big, small) = (1, 3) 27.9 k, (1, 9) 27.4 k, (3, 3) 26.2 k, (3, 9) 25.8 k, (1, 1) 26.6 k
+  static const int knob_wgs = getenv("HIPAC_WG_TARGET") ? atoi(getenv("HIPAC_WG_TARGET")) : 1536;
+  const int ntap_wg = stem ? 7 : (d.ks == 1 ? 1 : (big ? knob_big : knob_small));  // taps per workgroup (they share the dY tile)
+  const int tiles = stem ? 1 : (d.ks * d.ks / ntap_wg) * (d.cout / TC) * (d.cin / TC);
   // split the pixel axis so that the launch has ~1536 workgroups (6 per CU); slices bounded by the partials buffer
-  long long slices = (1536 + tiles - 1) / tiles;
+  long long slices = (knob_wgs + tiles - 1) / tiles;
   const long long cap = (long long)(kWgPartBytes / (pf * 4));
   if (slices > cap) slices = cap;
   if (slices < 1) slices = 1;
@@ -658,16 +729,18 @@ static int conv_wgrad_h(const AmpCtx& c, int i, int n, const h16* X, const h16* 
   if (chunk < 128) chunk = 128;
   slices = (M + chunk - 1) / chunk;
   dim3 grid(tiles, (unsigned)slices);
-  if (stem)
-    hipLaunchKernelGGL((wgrad_f16_kernel<64, true>), grid, dim3(256), 0, c.s, dY, X, part, 64, 3, 7, 2, 112, 224, M, (int)chunk);
-  else if (big)
-    hipLaunchKernelGGL((wgrad_f16_kernel<128, false>), grid, dim3(256), 0, c.s, dY, X, part, d.cout, d.cin, d.ks, d.stride, d.hout,
-                       d.hin, M, (int)chunk);
-  else
-    hipLaunchKernelGGL((wgrad_f16_kernel<64, false>), grid, dim3(256), 0, c.s, dY, X, part, d.cout, d.cin, d.ks, d.stride, d.hout,
-                       d.hin, M, (int)chunk);
+#define HIPAC_WG(TC_, NT_, ST_)                                                                                          \
+  hipLaunchKernelGGL((wgrad_f16_kernel<TC_, NT_, ST_>), grid, dim3(256), 0, c.s, dY, X, part, d.cout, d.cin, d.ks, d.stride, \
+                     d.hout, d.hin, M, (int)chunk)
+  if (stem) HIPAC_WG(64, 7, true);
+  else if (big && ntap_wg == 3) HIPAC_WG(128, 3, false);
+  else if (big) HIPAC_WG(128, 1, false);
+  else if (ntap_wg == 9) HIPAC_WG(64, 9, false);
+  else if (ntap_wg == 3) HIPAC_WG(64, 3, false);
+  else HIPAC_WG(64, 1, false);
+#undef HIPAC_WG
   const long long total = (long long)conv_w_floats(i);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, (const float*)part, (int)slices,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, c.s, (const float*)part, (int)slices,
                      grads + param_offset(i), d.cout, d.cin, d.ks, stem ? 1 : 0, accumulate);
   return (int)hipGetLastError();
 }
@@ -723,7 +796,7 @@ int hipac_train_amp_encoder_forward(const float* params, float* stats, const flo
   TRY(conv_forward_h(0, (const h16*)(ws + p.xin), wpack, zb, pre(0), n, s, zp));
   TRY(bn_forward_h(c, 0, n, nullptr, 1));
   {
-    const long long total = (long long)n * 56 * 56 * 64;
+    const long long total = (long long)n * 56 * 56 * 8;  // 8 channels per thread
     hipLaunchKernelGGL(maxpool_idx_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16*)post(0),
                        (h16*)(ws + p.pool), (unsigned char*)(ws + p.pool_idx), total);
     TRY((int)hipGetLastError());
@@ -826,7 +899,7 @@ int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, i
     }
   }
   {
-    const long long total = (long long)n * 112 * 112 * 64;
+    const long long total = (long long)n * 112 * 112 * 8;  // 8 channels per thread
     hipLaunchKernelGGL(maxpool_bwd_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16*)gA,
                        (const unsigned char*)(ws + p.pool_idx), gB, total);
     TRY((int)hipGetLastError());
