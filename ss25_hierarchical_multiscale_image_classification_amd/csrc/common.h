@@ -104,6 +104,8 @@ struct Net {
   char* zero_page;  // device, 256 zero bytes: DMA source for out-of-image conv taps
   unsigned short* lut_t;  // device, T[3][256]: (v/255 - mean)/std in fp32, rounded to T (uint8 input path)
   float* lut_f32;         // device, float[3][256]: the same table unrounded (fp16x3 mode, uint8 input)
+  float* bias_c2p[3];     // device, float[Cout]: bias of block0.conv2 + bias of the projection, stages 2-4 (folded projection)
+  int projk;              // 1: layers 3, 4 fold the projection shortcut into the block's second conv (HIPAC_PROJK, default 1)
 };
 
 // Workspace plan.  The trunk runs in two phases so every launch fills the chip:

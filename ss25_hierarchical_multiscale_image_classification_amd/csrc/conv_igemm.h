@@ -611,13 +611,19 @@ constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) 
 // SPLIT: fp16 (hi, lo) pairs, see conv_glds_kernel; virtual chunk 3c + 1 (Wlo x Xhi) reuses the band of 3c.
 // WM_ x WN_ = the 4 waves as pixel parts x channel parts; MINW = waves per SIMD the register budget is set for (1: one
 // 512-register wave per SIMD with a 128 x 128 tile -- 0.5 LDS fragment reads per MFMA instead of 0.75).
+// PCIN > 0 (second conv of a down-sampling BasicBlock): the block's 1x1 / stride 2 projection shortcut is folded in as
+// PCIN / 64 extra K steps -- the "band" of such a step is a GATHER of the block input's pixels (2y, 2x), 64 channels
+// each, placed where the centre tap reads, the weight tile comes from the projection's [COUT][PCIN] matrix, and `bias`
+// is the sum of both biases: conv2 + projection accumulate in ONE fp32 accumulator, the shortcut map (one HBM round
+// trip) and the projection launch disappear.  `resid` is then the block input [n][2H][2W][PCIN], `wgt_p` the projection.
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32,
-          bool SPLIT = false, int WM_ = 2, int WN_ = 2, int MINW = 2>
+          bool SPLIT = false, int WM_ = 2, int WN_ = 2, int MINW = 2, int PCIN = 0>
 __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                               const float* __restrict__ bias,
                                                               const T* __restrict__ resid, void* __restrict__ outp,
                                                               int M, int n_img, int n_mtiles,
-                                                              const char* __restrict__ zero_page) {
+                                                              const char* __restrict__ zero_page,
+                                                              const T* __restrict__ wgt_p = nullptr) {
   using E = Elem<T>;
   using frag = typename E::frag;
   constexpr int RC = CIN / 64;                      // real 64-channel chunks
@@ -636,7 +642,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   constexpr int W_BYTES = BN * 128;
   constexpr int WPW = BN / 8 / 4;                    // W pieces per wave per tap
   constexpr int NTILES_N = COUT / BN;
-  constexpr int NSTEP = 9 * CC;
+  constexpr int PCC = PCIN / 64;                    // projection K steps (0: no folded projection)
+  constexpr int NSTEP = 9 * CC + PCC;
+  static_assert(PCIN % 64 == 0 && (PCIN == 0 || (!RESID && !SPLIT)), "folded projection replaces the residual input");
   static_assert((BM == 128 || BM == 256 || BM == 512) && WTN % 32 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
   static_assert((BN / 8) % 4 == 0, "W piece split");
   static_assert(NSW == 2 || NSW == 3, "weight ring depth");
@@ -699,13 +707,49 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   // weight DMA through a buffer descriptor: per-lane 32-bit row offset in a VGPR (computed once per
   // tile), the tap / chunk offset in an SGPR -- no per-piece address arithmetic in the tap loop
   const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
+  int wp_off[PCC > 0 ? WPW : 1];
+  if constexpr (PCC > 0) {
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int row = (wave + 4 * i) * 8 + prow;
+      wp_off[i] = ((n0 + row) * PCIN + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+  }
+  const rsrc_t wp_rsrc = make_rsrc(PCC > 0 ? reinterpret_cast<const char*>(wgt_p) : w_b, COUT * (PCC > 0 ? PCIN : KTOT) * 2);
   auto issue_w = [&](int step, int slot_) {  // weights of step = cc*9 + tap: K offset (tap*CIN + cc*64)
+    if (PCC > 0 && step >= 9 * CC) {  // uniform: a projection step, 64 input channels of the 1x1 matrix
+      const int kofs_bytes = (step - 9 * CC) * 128;
+      static_for<WPW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        buffer_load_lds16(wp_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, wp_off[PCC > 0 ? i : 0], kofs_bytes);
+      });
+      return;
+    }
     const int cc = step / 9, tap = step - cc * 9;
     const int kofs_bytes = (tap * VCIN + cc * 64) * 2;
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
     });
+  };
+  // folded projection: the block input's pixel (2y, 2x) of every output pixel of the tile, 64 channels of chunk pc, at the
+  // slot the centre tap reads for that output pixel (q0 = m - mstart + 2)
+  auto issue_gather = [&](int pc) {
+    if constexpr (PCC > 0) {
+      const int npx_ = mlast - m0 + 1;
+      const int first = W + 3, last = first + npx_ - 1;  // slots that hold pixels
+      for (int p = wave + (first >> 3); p <= (last >> 3); p += 4) {
+        const int q = p * 8 + prow;
+        const int mm = m0 + q - first;
+        const bool ok = q >= first && q <= last;
+        const int b = mm / (H * W), rem = mm - b * (H * W), y = rem / W, x = rem - y * W;
+        const int schunk = dchunk ^ ((q >> 1) & 7);
+        const char* src = ok ? reinterpret_cast<const char*>(resid) +
+                                   ((((size_t)b * (2 * H) + 2 * y) * (2 * W) + 2 * x) * PCIN + pc * 64 + schunk * 8) * 2
+                             : zero_page + dchunk * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
+      }
+    }
   };
 
   // ---- consumer side: slot of this lane's two output pixels for tap (0, centre column) ----
@@ -864,6 +908,44 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
         // step's first LDS reads
         if (kk == HIPAC_HALO_W_ISSUE_KK && s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
 #endif
+      }
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  if constexpr (PCC > 0) {
+    // ---- the folded projection: PCC more K steps, centre tap only (no image-edge cases: pixel (2y, 2x) always exists)
+    for (int pc = 0; pc < PCC; ++pc, ++s) {
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
+      issue_gather(pc);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+      const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+      int abase[MTW], asw[MTW];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) abase[i] = q0[i] << 7, asw[i] = ((q0[i] >> 1) & 7) << 4;
+      frag af[2][MTW], wf[2][NT];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) af[0][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[0] ^ asw[i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[0][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[0]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+            af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[kk + 1] ^ asw[i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[kk + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
       }
       __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2360,7 +2442,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     const int n_vtiles = mt8 * (COUT / BN);
     dim3 grid(n_vtiles < 256 ? n_vtiles : 256);  // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
-                       n_mtiles, zero_page);
+                       n_mtiles, zero_page, (const T*)nullptr);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
     constexpr int BN = COUT >= 128 ? 128 : 64;
     // 256-pixel tiles (each wave 128 px x 64 ch: 0.75 LDS reads per MFMA, half the weight DMA per
@@ -2379,7 +2461,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     const int n_vtiles = mt8 * (COUT / BN);
     dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);  // persistent; both are multiples of 8
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
-                       n_mtiles, zero_page);
+                       n_mtiles, zero_page, (const T*)nullptr);
   } else {
     using C = TileCfg<COUT>;
     constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
@@ -2394,6 +2476,31 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out,
                        M, n_mtiles, zero_page, (const T*)nullptr, (const float*)nullptr, (void*)nullptr);
   }
+  return (int)hipGetLastError();
+}
+
+// second conv of a down-sampling block with the 1x1 / stride 2 projection folded in as extra K steps (halo kernel, PCIN):
+// tmp = relu(conv1(x)) -> out = relu(conv2(tmp) + proj(x) + b2 + bp)
+template <typename T, int CO, int HO, int PCIN>
+static int launch_conv_projk(const void* tmp, const ConvW& w2, const ConvW& wp, const float* bias_sum, const void* xblk, void* out,
+                             int n, hipStream_t s, const char* zero_page) {
+  constexpr int BN = 128;
+  constexpr int A256 = halo_band_pieces(HO, 256) * 1024;
+  constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
+  constexpr int A_BYTES = halo_band_pieces(HO, BM) * 1024;
+  constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;
+  constexpr int STG = 4 * 32 * (BN / 2 * 4 + 16);
+  constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
+  auto kern = conv3x3_halo_kernel<T, CO, CO, HO, HO, BM, BN, NSW, true, false, false, false, 2, 2, 2, PCIN>;
+  static bool attr_done[kMaxDevices] = {};
+  if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+  const int M = n * HO * HO;
+  const int n_mtiles = (M + BM - 1) / BM;
+  const int mt8 = (n_mtiles + 7) / 8 * 8;
+  const int n_vtiles = mt8 * (CO / BN);
+  dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)tmp, (const T*)w2.w, bias_sum, (const T*)xblk, out, M, n, n_mtiles,
+                     zero_page, (const T*)wp.w);
   return (int)hipGetLastError();
 }
 
@@ -2487,6 +2594,19 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   }
   // block 0
   const void* idt = x;
+  if constexpr (STRIDE == 2 && sizeof(T) == 2 && !SPLIT && CO >= 256) {
+    if (net.projk && net.bias_c2p[stage - 1]) {
+      // layers 3, 4: plain 3x3/2 entry conv; the projection rides in the SECOND conv as extra K steps (its op slot is empty)
+      if (ops.take())
+        HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false, false, false>(x, bw[0], nullptr, tmp, n, s, z)));
+      (void)ops.take();
+      if (ops.take())
+        HIPAC_TRY((launch_conv_projk<T, CO, HO, CI>(tmp, bw[1], net.down[stage - 1], net.bias_c2p[stage - 1], x, o0, n, s, z)));
+      if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false, false, SPLIT>(o0, bw1[0], nullptr, tmp, n, s, z)));
+      if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST, false, SPLIT>(tmp, bw1[1], o0, o1, n, s, z)));
+      return 0;
+    }
+  }
   if constexpr (STRIDE == 2 && sizeof(T) == 2 && HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
     // one launch: conv1 and the projection shortcut (the op slot of the projection stays empty).
     // Not for layer4: its second accumulator set pushes the kernel past 256 registers, i.e. to

@@ -448,6 +448,8 @@ void hipac_weights_free(hipac_weights_t* w) {
   if (w->net.zero_page) (void)hipFree(w->net.zero_page);
   if (w->net.lut_t) (void)hipFree(w->net.lut_t);
   if (w->net.lut_f32) (void)hipFree(w->net.lut_f32);
+  for (int i = 0; i < 3; ++i)
+    if (w->net.bias_c2p[i]) (void)hipFree(w->net.bias_c2p[i]);
   if (w->lane_stream) (void)hipStreamDestroy(w->lane_stream);
   delete w;
 }
@@ -488,6 +490,19 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     if (!rc) rc = pack_conv(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0) rc = pack_conv(params->down[s - 1], ch[s], cin, 1, eps, precision, false, &w->net.down[s - 1]);
   }
+  for (int st = 1; st < 4 && !rc && !wide_mode(precision); ++st) {
+    // block0.conv2's bias + the projection's, for the kernel that accumulates both into one accumulator
+    const hipac_convbn_t& a = params->block[2 * st][1];
+    const hipac_convbn_t& b = params->down[st - 1];
+    std::vector<float> bs(ch[st]);
+    for (int o = 0; o < ch[st]; ++o) {
+      const double sa = (double)a.bn_gamma[o] / sqrt((double)a.bn_var[o] + (double)eps);
+      const double sb = (double)b.bn_gamma[o] / sqrt((double)b.bn_var[o] + (double)eps);
+      bs[o] = (float)((double)a.bn_beta[o] - (double)a.bn_mean[o] * sa) + (float)((double)b.bn_beta[o] - (double)b.bn_mean[o] * sb);
+    }
+    rc = upload(bs.data(), bs.size() * 4, (void**)&w->net.bias_c2p[st - 1]);
+  }
+  w->net.projk = env_int("HIPAC_PROJK", 1, 0, 1);
   if (!rc) {
     const char zeros[256] = {0};
     rc = upload(zeros, sizeof(zeros), (void**)&w->net.zero_page);

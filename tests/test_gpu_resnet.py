@@ -194,6 +194,37 @@ def test_uint8_strip_kernel_against_oracle(prec):
     assert rel(fb[[0, 150, 299]], ref_fb) <= TOL[prec]["feat"]
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_folded_projection_against_separate_projection(monkeypatch, prec):
+    """Layers 3 and 4 fold the block's 1x1/2 projection shortcut into its SECOND conv (extra K steps of the halo kernel
+    on a gather of the block input, one fp32 accumulator for conv2 + projection).  HIPAC_PROJK=0 runs the projection as
+    its own accumulator / launch and adds its ROUNDED map in conv2's epilogue: same sums, one rounding fewer -- block
+    outputs agree to a few units of the storage type's last place (and both agree with the oracle within the mode's bound)."""
+    sd = synth.seeded_resnet18_state_dict(6, num_classes=2)
+    u8 = synth.synth_patches_u8(9, seed=12)
+    x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
+    taps = {}
+    ref_f, ref_l = R.resnet18_forward(x, sd, taps)
+    net = capi.PackedResNet18(sd, precision=prec)
+    f1, l1, _ = net.forward(u8.cuda(), want_logits=True)
+    t1 = {i: net.tap(9, i).clone() for i in (6, 8)}  # layer3.0, layer4.0 block outputs
+    monkeypatch.setenv("HIPAC_PROJK", "0")
+    net0 = capi.PackedResNet18(sd, precision=prec)
+    f0, l0, _ = net0.forward(u8.cuda(), want_logits=True)
+    eps = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    for i, name in ((6, "layer3.0"), (8, "layer4.0")):
+        assert rel(t1[i], taps[name]) <= TOL[prec]["tap"] and rel(net0.tap(9, i), taps[name]) <= TOL[prec]["tap"]
+        assert rel(t1[i], net0.tap(9, i)) <= 8 * eps, (name, rel(t1[i], net0.tap(9, i)))
+    assert rel(f1, ref_f) <= TOL[prec]["feat"] and rel(l1, ref_l) <= TOL[prec]["out"]
+    assert rel(f0, ref_f) <= TOL[prec]["feat"] and rel(l0, ref_l) <= TOL[prec]["out"]
+    # ragged tile ends: 520 patches = a group whose last 256-pixel tile is partial at 14 x 14 and at 7 x 7
+    big = synth.synth_patches_u8(520, seed=13, device="cuda")
+    fb0, _, _ = net0.forward(big)
+    monkeypatch.delenv("HIPAC_PROJK")
+    fb1, _, _ = net.forward(big)
+    assert rel(fb1, fb0) <= TOL[prec]["feat"]
+
+
 def test_sub_batching_and_determinism(monkeypatch):
     # internal schedule: early layers in sub-batches, late layers in groups.  Shrink both so
     # 131 patches = group 96 (sub-batches 48 + 48) + ragged group 35.
