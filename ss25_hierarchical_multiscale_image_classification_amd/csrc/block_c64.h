@@ -91,16 +91,6 @@ __device__ __forceinline__ void c64_strip_mfma(const typename Elem<T>::frag (&wr
 #endif
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {  // a.upper <-> b.lower (32-lane rows)
-  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0];
-  b = r[1];
-}
-#else
-__device__ inline void permlane32_swap(unsigned&, unsigned&) {}
-#endif
-
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 // ReLU on a dword of two T (bf16 | fp16): the sign bit decides, so it is a packed signed-integer max with 0
 // (== rounding the fp32 ReLU: rounding keeps the sign, -0 becomes +0)

@@ -241,6 +241,40 @@ __device__ inline rsrc_t make_rsrc(const void*, int) { return {}; }
 __device__ inline void buffer_load_lds16(rsrc_t, void*, int, int) {}
 #endif
 
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+template <typename T> struct PackPair;  // two exactly representable floats -> one dword of two T (lo, hi)
+template <> struct PackPair<_Float16> {
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));  // exact inputs: the rounding mode is moot
+  }
+  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    // round-to-nearest-even, as every other store of T in this library; one packed conversion
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+  }
+};
+template <> struct PackPair<__bf16> {
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+  }
+  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+  }
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {  // a.upper <-> b.lower (32-lane rows)
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#else
+__device__ inline void permlane32_swap(unsigned&, unsigned&) {}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
@@ -601,6 +635,12 @@ static __device__ unsigned long long g_halo_stamps[8];
 #ifndef HIPAC_HALO_GRID
 #define HIPAC_HALO_GRID 512  // persistent halo workgroups: 2 per CU x 256 CUs
 #endif
+#ifndef HIPAC_HALO_DIRECT_EPI
+#define HIPAC_HALO_DIRECT_EPI 0  // 1: epilogue straight from the accumulators (v_permlane32_swap pairs the lane halves), no LDS
+                                 // staging.  Bit-identical; measured NOT faster (trunk 3.65 vs 3.59 us per patch): the epilogue
+                                 // shrinks 13 k -> 8.6 k cycles without a residual, but 32-byte runs per pixel make the residual
+                                 // reads and the stores slower than the staged form's full 128-byte lines
+#endif
 constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) / 8; }  // 8-pixel (1 KB) pieces
 
 // NSW = depth of the weight ring (2, or 3 where LDS leaves room for two workgroups per CU).
@@ -791,6 +831,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   constexpr int IPT = 32 * CPW / 64;                // items per lane and sub-tile
   constexpr int SROWW = WTN * 4 + 16;               // staging row: WTN fp32 + pad
   static_assert(64 % CPW == 0 && (32 * CPW) % 64 == 0, "epilogue items");
+  constexpr bool DIRECT = HIPAC_HALO_DIRECT_EPI && !SPLIT && sizeof(T) == 2 && IPT == 2 * NT;
   static_assert(4 * 32 * SROWW <= S_BYTES, "per-wave staging fits the ring region");
   const int e_c0 = n0 + wn * WTN + (lane % CPW) * 8;  // first of this lane's 8 output channels
   const int e_px = lane / CPW;                        // pixel of item k: e_px + k * (64 / CPW)
@@ -808,6 +849,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
         if constexpr (SPLIT) {
           rv[0][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * OPIX + e_c0);
           rv[1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * OPIX + COUT + e_c0);
+        } else if constexpr (DIRECT) {
+          // item k = (channel tile j, pair qp): this lane's pixel r, the 8 channels it will also store (16 qp + 8 h)
+          int md = m0 + wm * (MTW * 32) + i * 32 + r;
+          md = md < M ? md : M - 1;
+          rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)md * COUT + n0 + wn * WTN + (k >> 1) * 32 + 16 * (k & 1) + 8 * h);
         } else {
           rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0);
         }
@@ -964,6 +1010,63 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
     if (mtn < n_mtiles) issue_band_of(mtn * BM, 0);
   }
   unsigned char* const Sl = Wbuf + wave * (32 * SROWW);  // this wave's private staging
+  if constexpr (DIRECT) {
+    // Straight from the accumulators: lane (r, h) holds pixel r of the sub-tile, channels 8q + 4h .. +3 of every 32-wide
+    // tile.  Bias, residual, ReLU and the rounding happen there; one v_permlane32_swap per packed dword then pairs the
+    // lane halves so that every lane stores 16 contiguous bytes (channels 16 qp + 8 h .. +7) -- no LDS round trip, no
+    // waits between sub-tiles.  The residual arrives in the stored layout and is un-paired by the same swap.  Same
+    // additions in the same order as the staged form: bit-identical results.
+    float4 bv[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(bias + n0 + wn * WTN + j * 32 + 8 * q + 4 * h);
+    static_for<MTW>([&](auto SUB) {
+      constexpr int i = decltype(SUB)::value;
+      if constexpr (i + 1 < MTW) load_resid(std::integral_constant<int, i + 1>{});
+      const int m = m0 + wm * (MTW * 32) + i * 32 + r;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        unsigned P[4][2];
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          unsigned rd[4] = {0u, 0u, 0u, 0u};
+          if constexpr (RESID) {
+            const u32x4 t = __builtin_bit_cast(u32x4, rv[i & 1][2 * j + qp]);
+            rd[0] = t[0], rd[1] = t[1], rd[2] = t[2], rd[3] = t[3];
+            permlane32_swap(rd[0], rd[2]);  // -> (rd[0], rd[1]) = channels of q = 2 qp, (rd[2], rd[3]) = those of q = 2 qp + 1
+            permlane32_swap(rd[1], rd[3]);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const int q = 2 * qp + qq;
+            float v0 = acc[i][j][4 * q + 0] + bv[j][q].x, v1 = acc[i][j][4 * q + 1] + bv[j][q].y;
+            float v2 = acc[i][j][4 * q + 2] + bv[j][q].z, v3 = acc[i][j][4 * q + 3] + bv[j][q].w;
+            if constexpr (RESID) {
+              const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, u32x2{rd[2 * qq], rd[2 * qq + 1]});
+              v0 += (float)rr[0], v1 += (float)rr[1], v2 += (float)rr[2], v3 += (float)rr[3];
+            }
+            if constexpr (RELU) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
+            if constexpr (OUTF32) {
+              if (m < M)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * COUT + n0 + wn * WTN + j * 32 + 8 * q + 4 * h) =
+                    make_float4(v0, v1, v2, v3);
+            } else {
+              P[q][0] = PackPair<T>::pack_rn(v0, v1);
+              P[q][1] = PackPair<T>::pack_rn(v2, v3);
+            }
+          }
+          if constexpr (!OUTF32) {
+            permlane32_swap(P[2 * qp][0], P[2 * qp + 1][0]);
+            permlane32_swap(P[2 * qp][1], P[2 * qp + 1][1]);
+            if (m < M)
+              *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + n0 + wn * WTN + j * 32 + 16 * qp + 8 * h) =
+                  u32x4{P[2 * qp][0], P[2 * qp][1], P[2 * qp + 1][0], P[2 * qp + 1][1]};
+          }
+        }
+      }
+    });
+  } else
   static_for<MTW>([&](auto SUB) {
     constexpr int i = decltype(SUB)::value;
     if constexpr (SPLIT) {
@@ -1355,30 +1458,6 @@ __device__ __forceinline__ void buffer_load_lds4(rsrc_t rs, void* lds, int voffs
 #else
 __device__ inline void buffer_load_lds4(rsrc_t, void*, int, int) {}
 #endif
-typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-
-template <typename T> struct PackPair;  // two exactly representable floats -> one dword of two T (lo, hi)
-template <> struct PackPair<_Float16> {
-  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));  // exact inputs: the rounding mode is moot
-  }
-  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    // round-to-nearest-even, as every other store of T in this library; one packed conversion
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
-  }
-};
-template <> struct PackPair<__bf16> {
-  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-  }
-  static __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-  }
-};
-
 constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 
 // ---------------------------------------------------------------------------------------
