@@ -161,7 +161,7 @@ def test_classifier_step_against_oracle_autograd():
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     x, y = torch.randn(8, 3, 224, 224), torch.tensor([0, 1, 1, 0, 0, 0, 1, 0])
     w = torch.tensor([1.0, 2.5])
-    tr = TN.NativeClassifierTrainer(sd, device="cuda", lr=1e-4, class_weights=w)
+    tr = TN.NativeClassifierTrainer(sd, device="cuda", lr=1e-4, class_weights=w, precision="fp32")  # (fp16: test_gpu_train_amp.py)
     loss, logits = tr.forward_backward(x.cuda(), y.cuda())
     masks = patterns(tr.encoder, 0)
     from oracle.resnet18_ref import canonical_state_dict
