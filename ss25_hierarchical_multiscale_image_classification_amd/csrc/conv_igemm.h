@@ -2481,7 +2481,10 @@ static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
 #endif
 // Tile shape per layer: COUT = 64 -> 256 pixels x 64 channels (4 waves);
 // otherwise 128 x 128 (4 waves, 4-stage ring).
-template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = 128, NSTAGE = HIPAC_NSTAGE_A; };
+#ifndef HIPAC_BN_A
+#define HIPAC_BN_A 128
+#endif
+template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, bool RELU, bool RESID,
