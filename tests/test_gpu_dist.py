@@ -80,6 +80,32 @@ def test_cli_world_size_reports_a_failing_rank(tmp_path):
     assert r.returncode != 0 and "exited with code" in r.stderr
 
 
+def test_cli_train_world_size_two(tmp_path):
+    """`main.py --train_strategy --strategy weighted_loss --world_size 2`: the launcher starts two ranks, each takes its
+    share of every global batch (per-replica batch-norm, CE over the gathered logits, gradients all-reduced), rank 0
+    prints the epoch line once and writes the checkpoint in the reference's key layout (src/main.py:605)."""
+    from PIL import Image
+
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier
+
+    rng = np.random.RandomState(0)
+    root = tmp_path / "data" / "patches" / "level_3"
+    for sl in range(4):
+        d = root / f"tumor_{sl:03d}"
+        d.mkdir(parents=True)
+        for k in range(6):
+            lab = "tumor" if (k + sl) % 2 == 0 else "normal"
+            Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8), "RGB").save(d / f"tumor_{sl:03d}_x{224 * k}_y0_{lab}.png")
+    cmd = [sys.executable, os.path.join(ROOT, "src", "main.py"), "--train_strategy", "--strategy", "weighted_loss", "--patch_level", "3",
+           "--data_root", str(tmp_path / "data"), "--epochs", "1", "--batch_size", "4", "--max_steps", "2", "--precision", "fp16",
+           "--world_size", "2", "--dist_backend", "gloo", "--one_device", "--rank_timeout", "600"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Epoch 1, Train Loss") == 1  # rank 0 only
+    out = torch.load(tmp_path / "src" / "models" / "resnet18_patch_classifier_weighted_loss.pth", map_location="cpu", weights_only=True)
+    assert set(out) == set(ResNet18Classifier().state_dict()) and all(bool(torch.isfinite(v.float()).all()) for v in out.values())
+
+
 def test_two_rank_classifier_step(tmp_path):
     """Two ranks, 4 images each, class weights (1, 2.5) and DIFFERENT class mixes per rank: the loss both ranks report
     and the gradients after the SUM all-reduce are those of CrossEntropyLoss(weight) over the gathered logits -- sum_i

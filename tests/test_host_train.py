@@ -53,6 +53,29 @@ def test_dataloaders_split_by_slide_and_augment_only_tumour(tmp_path):
     assert (labels == 0).sum() == (labels == 1).sum()  # validation set balanced (:446-458)
 
 
+def test_dataloaders_share_every_global_batch_over_the_ranks(tmp_path):
+    """world > 1 (`main.py --world_size N`): every rank builds the same datasets (same host-side seed) and draws ITS
+    chunk of every global batch -- what DataParallel's scatter hands replica r (src/main.py:481-482); the validation
+    samples are shared out as contiguous ranges, each scored exactly once."""
+    import random
+
+    root = png_tree(str(tmp_path), slides=5, per_slide=9)
+    world, B = 3, 6
+    per_rank = []
+    for r in range(world):
+        random.seed(0)  # main.py seeds every rank identically before the datasets are built
+        tl, vl, tds, vds = train.get_dataloaders(root, 0.2, batch_size=B, rank=r, world=world)
+        per_rank.append(([p for _, _, paths in tl for p in paths], [len(paths) for _, _, paths in tl],
+                         [p for _, _, paths in vl for p in paths], list(tds.image_paths), len(vds)))
+    assert all(pr[3] == per_rank[0][3] for pr in per_rank)  # the same dataset order on every rank
+    n_train = len(per_rank[0][3])
+    assert all(pr[1] == per_rank[0][1] for pr in per_rank) and set(per_rank[0][1]) <= {B // world, (n_train % B) // world}
+    seen = [p for pr in per_rank for p in pr[0]]
+    assert len(seen) == len(set(seen)) and len(seen) >= n_train - (world - 1)  # each sample once; only a remainder is left out
+    val = [p for pr in per_rank for p in pr[2]]
+    assert len(val) == len(set(val)) == per_rank[0][4]  # the validation set, partitioned
+
+
 def test_augmentation_cores():
     img = Image.fromarray(np.random.RandomState(1).randint(0, 256, (64, 48, 3), dtype=np.uint8), "RGB")
     # hue shift by +-0.5 twice is the identity on the H channel (uint8 wrap), and 0 leaves HSV round-trip only
