@@ -716,10 +716,10 @@ static int conv_wgrad_h(const AmpCtx& c, int i, int n, const h16* X, const h16* 
   const int TC = big ? 128 : 64;
   static const int knob_big = getenv("HIPAC_WG_NTAP_BIG") ? atoi(getenv("HIPAC_WG_NTAP_BIG")) : 1;      // developer knobs; measured (2 x 1024 views, img/s):
   static const int knob_small = getenv("HIPAC_WG_NTAP_SMALL") ? atoi(getenv("HIPAC_WG_NTAP_SMALL")) : 3;  // (big, small) = (1, 3) 27.9 k, (1, 9) 27.4 k, (3, 3) 26.2 k, (3, 9) 25.8 k, (1, 1) 26.6 k
-  static const int knob_wgs = getenv("HIPAC_WG_TARGET") ? atoi(getenv("HIPAC_WG_TARGET")) : 1536;
+  static const int knob_wgs = getenv("HIPAC_WG_TARGET") ? atoi(getenv("HIPAC_WG_TARGET")) : 768;  // workgroups per launch: 256 23.0 k, 512 27.4 k, 768 28.5 k, 1536 27.9 k, 3072 27.1 k
   const int ntap_wg = stem ? 7 : (d.ks == 1 ? 1 : (big ? knob_big : knob_small));  // taps per workgroup (they share the dY tile)
   const int tiles = stem ? 1 : (d.ks * d.ks / ntap_wg) * (d.cout / TC) * (d.cin / TC);
-  // split the pixel axis so that the launch has ~1536 workgroups (6 per CU); slices bounded by the partials buffer
+  // split the pixel axis so that the launch has ~768 workgroups (3 per CU); slices bounded by the partials buffer
   long long slices = (knob_wgs + tiles - 1) / tiles;
   const long long cap = (long long)(kWgPartBytes / (pf * 4));
   if (slices > cap) slices = cap;

@@ -1,4 +1,4 @@
-for cfg in "3 9 1536" "1 9 1536" "3 3 1536" "1 3 1536" "3 9 768" "1 1 1536" "3 9 3072"; do
+for cfg in "1 3 256" "1 3 512" "1 3 640" "1 3 768"; do
   set -- $cfg
   HIPAC_WG_NTAP_BIG=$1 HIPAC_WG_NTAP_SMALL=$2 HIPAC_WG_TARGET=$3 python bench.py --workload simclr --steps 3 --warmup 1 --train_precision fp16 2>/dev/null | python -c "
 import json,sys
