@@ -404,30 +404,34 @@ struct hipac_weights {
   // large batches are split in two halves that run concurrently, one on the caller's stream
   // and one here, so the tail of every launch (partly filled last round of workgroups) is
   // covered by the other lane's kernels.  Fork / join with the caller's stream by events.
-  hipStream_t lane_stream = nullptr;
+  hipStream_t lane_stream = nullptr;       // lane 1
+  hipStream_t lane_stream_x[2] = {nullptr, nullptr};  // lanes 2, 3 (HIPAC_LANES = 3 | 4)
   int device = 0;  // the device that was current at pack time: weights, lane stream and kernel attributes live there
 };
+constexpr int kMaxLanes = 4;
 
 // Split of one forward call into lanes.  Each lane owns a whole workspace plan.
 struct Lanes {
-  int n;        // 1 or 2
-  int chunk;    // images handled by lane 0 (lane 1 takes the rest)
+  int n;        // 1 .. kMaxLanes
+  int chunk;    // images handled by every lane but the last (which takes the rest)
   Plan p;       // per-lane plan (sized for `chunk` images)
   size_t total; // workspace bytes
 };
 static Lanes make_lanes(int batch, int precision) {
   Lanes L;
   const Plan single = make_plan(batch, precision);
-  const int want = env_int("HIPAC_LANES", 2, 1, 2);
-  L.n = (want == 2 && batch >= 4 * single.bc) ? 2 : 1;
+  int want = env_int("HIPAC_LANES", 2, 1, kMaxLanes);
+  while (want > 1 && batch < 2 * want * single.bc) --want;  // every lane gets at least two sub-batches
+  L.n = want;
   if (L.n == 1) {
     L.chunk = batch, L.p = single, L.total = single.total;
     return L;
   }
-  L.chunk = ((batch + 1) / 2 + single.bc - 1) / single.bc * single.bc;  // whole sub-batches in lane 0
+  L.chunk = ((batch + L.n - 1) / L.n + single.bc - 1) / single.bc * single.bc;  // whole sub-batches per lane
+  while (L.n > 1 && (long long)(L.n - 1) * L.chunk >= batch) --L.n;                  // (rounding up may empty the last lanes)
   L.p = make_plan(L.chunk, precision);
   // run_ops / tap address the workspace with the single-lane plan of `batch`: keep room for it
-  L.total = 2 * L.p.total > single.total ? 2 * L.p.total : single.total;
+  L.total = (size_t)L.n * L.p.total > single.total ? (size_t)L.n * L.p.total : single.total;
   return L;
 }
 
@@ -451,6 +455,8 @@ void hipac_weights_free(hipac_weights_t* w) {
   for (int i = 0; i < 3; ++i)
     if (w->net.bias_c2p[i]) (void)hipFree(w->net.bias_c2p[i]);
   if (w->lane_stream) (void)hipStreamDestroy(w->lane_stream);
+  for (int i = 0; i < 2; ++i)
+    if (w->lane_stream_x[i]) (void)hipStreamDestroy(w->lane_stream_x[i]);
   delete w;
 }
 
@@ -534,6 +540,8 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   }
   // optional: without it forward simply runs single-lane
   if (hipStreamCreateWithFlags(&w->lane_stream, hipStreamNonBlocking) != hipSuccess) w->lane_stream = nullptr;
+  for (int i = 0; i < 2; ++i)
+    if (hipStreamCreateWithFlags(&w->lane_stream_x[i], hipStreamNonBlocking) != hipSuccess) w->lane_stream_x[i] = nullptr;
   *out = w;
   return 0;
 }
@@ -609,27 +617,42 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   };
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  if (L.n == 1 || !w->lane_stream) return run_lane(ws, 0, batch, s);
-  // fork: lane 1 (the handle's stream) starts after everything already queued on s
-  hipEvent_t fork = nullptr, join = nullptr;
-  HIPAC_CHECK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  hipError_t e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
-  if (e != hipSuccess) {
-    (void)hipEventDestroy(fork);
-    HIPAC_CHECK_HIP(e);
+  hipStream_t lane_s[kMaxLanes] = {s, w->lane_stream, w->lane_stream_x[0], w->lane_stream_x[1]};
+  int n_lanes = L.n;
+  for (int k = 1; k < n_lanes; ++k)
+    if (!lane_s[k]) n_lanes = 1;  // a stream could not be created at pack time: single lane
+  if (n_lanes == 1) {
+    if (L.n == 1) return run_lane(ws, 0, batch, s);
+    // the plan `p` is sized for one lane's chunk: walk the chunks one after another on the caller's stream
+    for (int i0 = 0; i0 < batch; i0 += L.chunk) {
+      int rc1 = run_lane(ws, i0, batch - i0 < L.chunk ? batch - i0 : L.chunk, s);
+      if (rc1) return rc1;
+    }
+    return 0;
   }
+  // fork: lanes 1.. (the handle's streams) start after everything already queued on s; join: s waits for all of them
+  hipEvent_t fork = nullptr, join[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  HIPAC_CHECK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  hipError_t e = hipSuccess;
+  for (int k = 1; k < n_lanes && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&join[k], hipEventDisableTiming);
   int rc = 0;
-  e = hipEventRecord(fork, s);
-  if (e == hipSuccess) e = hipStreamWaitEvent(w->lane_stream, fork, 0);
+  if (e == hipSuccess) e = hipEventRecord(fork, s);
   if (e == hipSuccess) {
-    rc = run_lane(ws + L.p.total, L.chunk, batch - L.chunk, w->lane_stream);
-    // join even after a failed launch so the caller's stream stays ordered behind lane 1
-    e = hipEventRecord(join, w->lane_stream);
-    if (rc == 0) rc = run_lane(ws, 0, L.chunk, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, join, 0);
+    for (int k = n_lanes - 1; k >= 1 && e == hipSuccess; --k) {
+      e = hipStreamWaitEvent(lane_s[k], fork, 0);
+      if (e != hipSuccess) break;
+      const int i0 = k * L.chunk, n = batch - i0 < L.chunk ? batch - i0 : L.chunk;
+      if (rc == 0) rc = run_lane(ws + (size_t)k * L.p.total, i0, n, lane_s[k]);
+      // join even after a failed launch so the caller's stream stays ordered behind every lane
+      e = hipEventRecord(join[k], lane_s[k]);
+    }
+    if (rc == 0 && e == hipSuccess) rc = run_lane(ws, 0, L.chunk, s);
+    for (int k = 1; k < n_lanes; ++k)
+      if (join[k] && e == hipSuccess) e = hipStreamWaitEvent(s, join[k], 0);
   }
   (void)hipEventDestroy(fork);  // released by the runtime once the recorded work has completed
-  (void)hipEventDestroy(join);
+  for (int k = 1; k < n_lanes; ++k)
+    if (join[k]) (void)hipEventDestroy(join[k]);
   HIPAC_CHECK_HIP(e);
   return rc;
 }
