@@ -1,9 +1,10 @@
 """Oracle: NT-Xent loss as the reference computes it.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED beyond
-closed-form known answers: src/models/simclr.py cannot be imported here (its
-top-level ``import torchvision.models`` fails) and the reference holds no
-fixture for the loss.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PINNED on the reference itself: src/models/simclr.py cannot be
+imported as a module here (its top-level ``import torchvision.models`` fails), but ``nt_xent_loss`` is pure torch;
+tests/golden/make_golden_ntxent.py compiles that one function definition from the reference file and stores its
+values and autograd gradients on seeded inputs (tests/golden/ntxent_golden.npz); tests/test_oracle_resnet.py holds
+this restatement to them (1e-6), tests/test_gpu_ntxent.py the HIP kernel (2e-5).
 
 Follows src/models/simclr.py:31-54 step for step:
   z = cat(z_i, z_j)            [2N, D]

@@ -43,3 +43,16 @@ def test_closed_form_and_errors():
         capi.ntxent_fwd_bwd(torch.zeros(4, 8), t)                 # CPU tensor: no fallback
     with pytest.raises(capi.HipacError):
         capi.ntxent_fwd_bwd(torch.zeros(4, 300).cuda(), t)        # d > 256
+
+
+def test_value_and_gradient_match_the_reference_function(golden_dir):
+    """Against the golden vectors the REFERENCE's own nt_xent_loss produced (tests/golden/make_golden_ntxent.py)."""
+    g = np.load(f"{golden_dir}/ntxent_golden.npz")
+    for k in range(4):
+        zi, zj, t = torch.from_numpy(g[f"c{k}_zi"]), torch.from_numpy(g[f"c{k}_zj"]), float(g[f"c{k}_t"])
+        loss, dz = capi.ntxent_fwd_bwd(torch.cat([zi, zj]).cuda(), t, want_grad=True)
+        want = float(g[f"c{k}_loss"])
+        assert abs(float(loss) - want) <= 2e-5 * max(1.0, abs(want))
+        n = zi.shape[0]
+        for got, ref in ((dz[:n].cpu(), g[f"c{k}_gi"]), (dz[n:].cpu(), g[f"c{k}_gj"])):
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-5 * float(np.abs(ref).max()) + 1e-9

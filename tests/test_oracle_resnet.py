@@ -69,3 +69,18 @@ def test_nt_xent_closed_form():
     s.fill_diagonal_(float("-inf"))
     manual = (-1.0 / T + torch.logsumexp(s, 1)).mean()
     assert torch.allclose(l2, manual, atol=1e-6)
+
+
+def test_ntxent_restatement_equals_the_reference_function(golden_dir):
+    """tests/golden/ntxent_golden.npz was produced by the REFERENCE's own nt_xent_loss (src/models/simclr.py:31-54,
+    compiled from its source by make_golden_ntxent.py): value and autograd gradient on four seeded cases."""
+    import numpy as np
+
+    g = np.load(f"{golden_dir}/ntxent_golden.npz")
+    for k in range(4):
+        zi, zj = torch.from_numpy(g[f"c{k}_zi"]).requires_grad_(True), torch.from_numpy(g[f"c{k}_zj"]).requires_grad_(True)
+        loss = ntxent_ref.nt_xent_loss_ref(zi, zj, float(g[f"c{k}_t"]))
+        loss.backward()
+        assert abs(float(loss) - float(g[f"c{k}_loss"])) <= 1e-6 * max(1.0, abs(float(g[f"c{k}_loss"])))
+        for got, want in ((zi.grad, g[f"c{k}_gi"]), (zj.grad, g[f"c{k}_gj"])):
+            assert float((got - torch.from_numpy(want)).abs().max()) <= 1e-6 * float(np.abs(want).max()) + 1e-12
