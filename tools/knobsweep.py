@@ -1,5 +1,5 @@
 """Developer tool (GPU box): whole-trunk patches/s for combinations of the per-call environment knobs.
-usage: python tools/knobsweep.py "HIPAC_SUBBATCH=256,512" "HIPAC_LANES=1,2" ..."""
+usage: python tools/knobsweep.py [--precision fp16x3] "HIPAC_SUBBATCH=256,512" "HIPAC_LANES=1,2" ..."""
 import itertools
 import os
 import sys
@@ -10,7 +10,11 @@ import torch  # noqa: E402
 from ss25_hierarchical_multiscale_image_classification_amd import capi, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision="bf16")
+prec = "bf16"
+if len(sys.argv) > 2 and sys.argv[1] == "--precision":
+    prec = sys.argv[2]
+    del sys.argv[1:3]
+net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision=prec)
 u8 = synth.synth_patches_u8(8192, seed=1, device=dev)
 axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[1:]]
 for combo in itertools.product(*[v for _, v in axes]):
