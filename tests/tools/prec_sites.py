@@ -64,7 +64,9 @@ with torch.no_grad():
             if n not in cache: cache[n] = diffuse(w)
             return cache[n]
         for nm, wq, aq in [('w RN only', lambda n, w: rn(w), ident_a), ('w diffuse only', wd, ident_a),
-                           ('w diffuse + a RN', wd, lambda n, a: rn(a)), ('w RN + a RN', lambda n, w: rn(w), lambda n, a: rn(a))]:
+                           ('w diffuse + a RN', wd, lambda n, a: rn(a)), ('w RN + a RN', lambda n, w: rn(w), lambda n, a: rn(a)),
+                           # the two-product variant (weights as (hi, lo) pairs = exact here, activations single fp16)
+                           ('w exact + a RN', ident_w, lambda n, a: rn(a))]:
             f, l = sim(x, sd, wq, aq)
             print(f'{nm:20s} feats {rel(f, rf):.2e} logits {rel(l, rl):.2e}')
     else:
