@@ -656,8 +656,12 @@ constexpr int halo_band_pieces(int W, int BM) { return (BM + 2 * W + 2 + 2 + 7) 
 // each, placed where the centre tap reads, the weight tile comes from the projection's [COUT][PCIN] matrix, and `bias`
 // is the sum of both biases: conv2 + projection accumulate in ONE fp32 accumulator, the shortcut map (one HBM round
 // trip) and the projection launch disappear.  `resid` is then the block input [n][2H][2W][PCIN], `wgt_p` the projection.
+// DBLW (SPLIT only, where the LDS budget allows a weight ring of two 2-tile slots): per real 64-channel chunk the K loop runs
+// nine DOUBLE steps -- the band of the hi plane against the weight tiles [Whi | Wlo] of a tap, two MFMAs per activation
+// fragment -- and nine single steps (lo plane x Whi): 18 barriers and (MTW + 2 NT) / (2 MTW NT) fragment reads per MFMA on two
+// thirds of the work instead of 27 barriers and (MTW + NT) / (MTW NT).
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32,
-          bool SPLIT = false, int WM_ = 2, int WN_ = 2, int MINW = 2, int PCIN = 0>
+          bool SPLIT = false, int WM_ = 2, int WN_ = 2, int MINW = 2, int PCIN = 0, bool DBLW = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                               const float* __restrict__ bias,
                                                               const T* __restrict__ resid, void* __restrict__ outp,
@@ -689,7 +693,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   static_assert((BN / 8) % 4 == 0, "W piece split");
   static_assert(NSW == 2 || NSW == 3, "weight ring depth");
   constexpr int STG_BYTES = 4 * 32 * (WTN * 4 + 16);  // 4 waves x [32 px][WTN fp32 + pad] epilogue staging
-  constexpr int S_BYTES = NSW * W_BYTES > STG_BYTES ? NSW * W_BYTES : STG_BYTES;  // ring, aliased by the staging
+  static_assert(!DBLW || (SPLIT && NSW == 2 && PCIN == 0), "double weight steps: split pairs, two ring slots");
+  constexpr int SLOT_BYTES = DBLW ? 2 * W_BYTES : W_BYTES;  // one ring slot
+  constexpr int S_BYTES = NSW * SLOT_BYTES > STG_BYTES ? NSW * SLOT_BYTES : STG_BYTES;  // ring, aliased by the staging
   static_assert(A_BYTES + S_BYTES <= 160 * 1024 / MINW, "LDS: MINW workgroups per CU");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -862,6 +868,90 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   };
 
   HALO_STAMP(t_start);
+  int s = 0;  // K step counter
+  if constexpr (DBLW) {
+    // ---- double weight steps (see the template note): step = (chunk c, phase, tap), phase 0 = hi plane x [Whi | Wlo]
+    constexpr int NSTEP2 = 18 * RC;
+    auto issue_w2 = [&](int step, int slot_) {
+      const int c = step / 18, rr = step - c * 18, ph = rr >= 9 ? 1 : 0, tap = rr - 9 * ph;
+      const int kofs_bytes = (tap * VCIN + 3 * c * 64) * 2;  // the hi_c block of this tap; lo_c follows 128 bytes on
+      static_for<WPW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        buffer_load_lds16(w_rsrc, Wbuf + slot_ * SLOT_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
+      });
+      if (ph == 0)
+        static_for<WPW>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          buffer_load_lds16(w_rsrc, Wbuf + slot_ * SLOT_BYTES + W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes + 128);
+        });
+    };
+    if (first_tile) issue_band(0);
+    issue_w2(0, 0);
+    for (int c2 = 0; c2 < 2 * RC; ++c2) {
+      const int ph = c2 & 1;
+      if (c2 > 0) {
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
+        issue_band(3 * (c2 >> 1) + 2 * ph);  // virtual chunk 3c = hi plane, 3c + 2 = lo plane
+      }
+#pragma unroll HIPAC_HALO_TAP_UNROLL
+      for (int tap = 0; tap < 9; ++tap, ++s) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = (kh - 1) * W + kw - 1;
+        const unsigned char* wst = Wbuf + (s & 1) * SLOT_BYTES;
+        const int tapmask = (kw == 0 ? 1 : 0) | (kw == 2 ? 2 : 0) | (kh == 0 ? 4 : 0) | (kh == 2 ? 8 : 0);
+        int abase[MTW], asw[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          const bool off_img = (eflags[i] & tapmask) != 0;
+          const int qt = q0[i] + toff;
+          const int q = off_img ? (qt & 1) : qt;
+          abase[i] = q << 7;
+          asw[i] = ((qt >> 1) & 7) << 4;
+        }
+        frag af[2][MTW], wf[2][2 * NT];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) af[0][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[0] ^ asw[i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[0][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[0]);
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf[0][NT + j] = *reinterpret_cast<const frag*>(wst + W_BYTES + j * 4096 + rdw[0]);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (kk + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+              af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(Abuf + abase[i] + (ck[kk + 1] ^ asw[i]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              wf[(kk + 1) & 1][j] = *reinterpret_cast<const frag*>(wst + j * 4096 + rdw[kk + 1]);
+            if (ph == 0) {
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                wf[(kk + 1) & 1][NT + j] = *reinterpret_cast<const frag*>(wst + W_BYTES + j * 4096 + rdw[kk + 1]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
+          if (ph == 0) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = E::mfma(wf[kk & 1][NT + j], af[kk & 1][i], acc[i][j]);
+          }
+          if (kk == 1 && s + 1 < NSTEP2) issue_w2(s + 1, (s + 1) & 1);  // its slot was freed by this step's barrier
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  } else {
   if (first_tile) issue_band(0);
 #pragma unroll
   for (int pstep = 0; pstep < NSW - 1; ++pstep)
@@ -869,7 +959,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
 #ifdef HIPAC_HALO_STAMPS
   unsigned long long t_first = 0;
 #endif
-  int s = 0;
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0 && (!SPLIT || cc % 3 != 1)) {  // (SPLIT: chunk 3c + 1 multiplies the band of 3c by the low weight halves)
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
@@ -960,6 +1049,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
     }
   }
 
+  }  // !DBLW
   if constexpr (PCC > 0) {
     // ---- the folded projection: PCC more K steps, centre tap only (no image-edge cases: pixel (2y, 2x) always exists)
     for (int pc = 0; pc < PCC; ++pc, ++s) {
@@ -2458,6 +2548,9 @@ static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
 #ifndef HIPAC_HALO_BM256
 #define HIPAC_HALO_BM256 1
 #endif
+#ifndef HIPAC_SPLIT_DBLW
+#define HIPAC_SPLIT_DBLW 1  // fp16x3 layer1: double weight steps (see conv3x3_halo_kernel's DBLW note)
+#endif
 #ifndef HIPAC_HALO_BIG
 #define HIPAC_HALO_BIG 0  // 1: layers 2-4 on one 512-register wave per SIMD (128 x 128 per wave)
 #endif
@@ -2532,10 +2625,13 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int A256 = halo_band_pieces(WI, 256) * 1024;
     constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
     constexpr int A_BYTES = halo_band_pieces(WI, BM) * 1024;
-    constexpr int NSW = (A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2;  // deepest ring that keeps 2 workgroups/CU
     constexpr int STG = 4 * 32 * (BN / 2 * 4 + 16);  // epilogue staging, aliases the ring
-    constexpr int LDS = A_BYTES + (NSW * BN * 128 > STG ? NSW * BN * 128 : STG);
-    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT>;
+    // fp16x3, narrow tiles: double weight steps where two 2-tile ring slots still leave two workgroups per CU (layer1)
+    constexpr bool DBLW = SPLIT && HIPAC_SPLIT_DBLW && (A_BYTES + 4 * BN * 128 <= 80 * 1024);
+    constexpr int NSW = DBLW ? 2 : ((A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2);  // deepest ring that keeps 2 workgroups/CU
+    constexpr int RING = NSW * BN * 128 * (DBLW ? 2 : 1);
+    constexpr int LDS = A_BYTES + (RING > STG ? RING : STG);
+    auto kern = conv3x3_halo_kernel<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT, 2, 2, 2, 0, DBLW>;
     static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
     if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
