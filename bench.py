@@ -252,12 +252,17 @@ def scan_slide_timed(net, slide, args, world, steps, warmup, dev):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         n_kept = step()
+        if world == 1:  # per-scan wall clock as well (diagnostic: a one-off cost shows as one slow scan)
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
+    scan_slide_timed.last_scans = [b - a for a, b in zip([t0] + marks[:-1], marks)]
     return dt / steps, n_all, n_kept
 
 
@@ -271,8 +276,9 @@ def wsi_object(net, args, rank, world, dev, sides):
         key = f"{side}x{side}"
         try:
             slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
-            s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, steps=2 if side <= 50000 else 1, warmup=1, dev=dev)
-            rec = {"s_per_slide": s_per, "windows": n_all, "kept": n_kept, "n_gpus": world, "slides": world,
+            s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, steps=2, warmup=1, dev=dev)
+            rec = {"s_per_slide": s_per, "scans_s": [round(t, 4) for t in getattr(scan_slide_timed, "last_scans", [])],
+                   "windows": n_all, "kept": n_kept, "n_gpus": world, "slides": world,
                    "kept_patches_per_s": world * n_kept / s_per if world == 1 else None,
                    "unique_source_GBps": world * sum(w * h * 3 for (w, h) in slide.level_dimensions) / s_per / 1e9}
             if rank == 0:

@@ -298,9 +298,12 @@ class PackedResNet18:
         allocating it per slide would go through hipMalloc whenever the caching allocator had let go of the block).
         Valid until the next call; a consumer on another stream must order itself after the forwards that read it."""
         need = n * PATCH * PATCH * 3
+        device = torch.device(device)
+        if device.index is None:  # "cuda" and "cuda:0" must compare equal, or the buffer is re-made on every call
+            device = torch.device(device.type, torch.cuda.current_device())
         buf = getattr(self, "_batch", None)
         if buf is None or buf.numel() < need or buf.device != device:
-            self._batch = None  # release before growing
+            buf = self._batch = None  # release BOTH references before growing: the old block must be free for the new one
             buf = self._batch = torch.empty(need, dtype=torch.uint8, device=device)
         return buf[:need].view(n, PATCH, PATCH, 3)
 

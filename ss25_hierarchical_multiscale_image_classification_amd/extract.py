@@ -102,7 +102,7 @@ class DeviceSlide:
             if wp > w:
                 buf[:, w:] = 0
             self.levels.append(buf)
-        self.device = dev
+        self.device = self.levels[0].device if self.levels else dev  # the indexed device ("cuda" alone != "cuda:0")
         self.polygons: Optional[list] = None
         self._masks: Dict[int, torch.Tensor] = {}
 
@@ -329,6 +329,21 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     def stride_of(level):
         return stride(level) if callable(stride) else stride
 
+    dbg = os.environ.get("HIPAC_SCAN_TIMES") == "1"  # developer aid: synchronise after every phase and print its wall clock
+    import time as _time
+
+    def _mark(label, t_prev):
+        if not dbg:
+            return t_prev
+        torch.cuda.synchronize(dev)
+        t = _time.perf_counter()
+        st = torch.cuda.memory_stats(dev)
+        print(f"[score_slide] {label}: {(t - t_prev) * 1e3:.1f} ms  (reserved {st['reserved_bytes.all.current'] / 2**30:.1f} GiB, "
+              f"allocated {st['allocated_bytes.all.current'] / 2**30:.1f} GiB, alloc retries {st['num_alloc_retries']}, "
+              f"segments {st['segment.all.current']})", flush=True)
+        return t
+
+    t_dbg = _mark("start", _time.perf_counter()) if dbg else 0.0
     with trace.span("window decisions, all levels"):
         lws = [LevelWindows(slide, lv, stride_of(lv)) for lv in levels]
         # the host's one wait: the kept counts of all levels in one small copy (the index lists themselves follow at once)
@@ -336,9 +351,11 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
     n_total = int(sum(counts))
     if n_total == 0:
         return (torch.empty((0, 512), device=dev), None, None, torch.empty((0, 4), dtype=torch.int32, device=dev))
+    t_dbg = _mark("decisions + counts", t_dbg)
     kepts = [lw.kept_index() for lw in lws]
     metas = torch.cat([lw.meta(k) for lw, k in zip(lws, kepts)])
     buf = net.batch_buffer(n_total, dev)
+    t_dbg = _mark("index lists, meta, batch buffer", t_dbg)
     with trace.span("gather kept windows"):
         done = 0
         for lw, k in zip(lws, kepts):
@@ -347,11 +364,13 @@ def score_slide(slide: DeviceSlide, net: capi.PackedResNet18, levels: Sequence[i
                 lw.patches(idx, out=buf[done:done + idx.shape[0]])
                 done += idx.shape[0]
     del lws  # the resampled planes (GBs at level 0) go back to the allocator before the forwards allocate
+    t_dbg = _mark("gather", t_dbg)
     out_chunks = []
     for lo in range(0, n_total, FWD):
         end = min(n_total, lo + FWD)
         with trace.span(f"resnet18 forward [{lo}:{end})"):
             out_chunks.append(net.forward(buf[lo:end], want_feats=True, want_logits=has_fc, want_labels=has_fc))
+    t_dbg = _mark("forwards", t_dbg)
     one = len(out_chunks) == 1
     feats = out_chunks[0][0] if one else torch.cat([c[0] for c in out_chunks])
     logits = (out_chunks[0][1] if one else torch.cat([c[1] for c in out_chunks])) if has_fc else None
