@@ -313,8 +313,8 @@ __device__ __forceinline__ void split_pair4(const float* v, f16x4& hi, f16x4& lo
 }
 
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
-          bool RELU, bool RESID, bool OUTF32, bool PROJ = false, bool SPLIT = false>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kernel(
+          bool RELU, bool RESID, bool OUTF32, bool PROJ = false, bool SPLIT = false, int WTM = 64>
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kernel(
     const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
     const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page,
     const T* __restrict__ wgt_p = nullptr, const float* __restrict__ bias_p = nullptr,
@@ -333,13 +333,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   constexpr int KTP = PROJ ? KT + CC : KT;          // + the projection's K tiles
   static_assert(!PROJ || (KS == 3 && STRIDE == 2 && !RESID && !OUTF32), "projection rides on 3x3/2 only");
   static_assert(!SPLIT || (std::is_same<T, _Float16>::value && !RESID), "split pairs are fp16");
-  constexpr int WM = BM / 64, WN = BN / 64, NWAVES = WM * WN;
+  static_assert(WTM == 64 || WTM == 128, "wave tile: 64 or 128 pixels x 64 channels");
+  constexpr int MT = WTM / 32;                     // 32-pixel sub-tiles per wave (4: 0.75 LDS fragment reads per MFMA instead of 1)
+  constexpr int WM = BM / WTM, WN = BN / 64, NWAVES = WM * WN;
   constexpr int APW = BM / 8 / NWAVES;  // 1-KiB A pieces per wave per K tile
   constexpr int WPW = BN / 8 / NWAVES;  // 1-KiB W pieces per wave per K tile
   constexpr int PPW = APW + WPW;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int NTILES_N = COUT / BN;
-  static_assert(BM % 64 == 0 && BN % 64 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
+  static_assert(BM % WTM == 0 && BN % 64 == 0 && COUT % BN == 0 && CIN % 64 == 0, "tile shape");
   static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "piece split");
   static_assert(NSTAGE >= 2 && NSTAGE * STAGE <= 160 * 1024, "LDS ring");
   static_assert((NSTAGE - 1) * PPW < 64, "vmcnt range");
@@ -425,12 +427,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   int rd[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) rd[kk] = r * 128 + (((2 * kk + h) ^ sw) << 4);
-  const int a_rd0 = wm * 64 * 128;
+  const int a_rd0 = wm * WTM * 128;
   const int w_rd0 = BM * 128 + wn * 64 * 128;
 
-  f32x16 acc[2][2], accp[PROJ ? 2 : 1][PROJ ? 2 : 1];
+  f32x16 acc[MT][2], accp[PROJ ? MT : 1][PROJ ? 2 : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -479,9 +481,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
     if (t + NSTAGE - 1 < KTP) issue_next();
     const unsigned char* st = ring + (t % NSTAGE) * STAGE;
     // fragment reads run one k16 step ahead of the MFMAs that consume them
-    frag af[2][2], wf[2][2];
+    frag af[2][MT], wf[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const frag*>(st + a_rd0 + i * 4096 + rd[0]);
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const frag*>(st + a_rd0 + i * 4096 + rd[0]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) wf[0][j] = *reinterpret_cast<const frag*>(st + w_rd0 + j * 4096 + rd[0]);
     __builtin_amdgcn_s_setprio(1);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
     for (int kk = 0; kk < 4; ++kk) {
       if (kk + 1 < 4) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
           af[(kk + 1) & 1][i] = *reinterpret_cast<const frag*>(st + a_rd0 + i * 4096 + rd[kk + 1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -497,14 +499,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
       }
       if (PROJ && t >= KT) {  // uniform: the last CC tiles feed the projection's accumulators
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             accp[PROJ ? i : 0][PROJ ? j : 0] =
                 E::mfma(wf[kk & 1][j], af[kk & 1][i], accp[PROJ ? i : 0][PROJ ? j : 0]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma(wf[kk & 1][j], af[kk & 1][i], acc[i][j]);
       }
@@ -517,8 +519,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
   // ---- projection epilogue: + bias -> NHWC store (no ReLU, no residual) -------------------
   if constexpr (PROJ) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + r;
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 32 + r;
       if (m >= M) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -547,8 +549,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void conv_glds_kerne
 
   // ---- epilogue: +bias (+residual) (ReLU) -> NHWC store ---------------------------------
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + r;
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + r;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2577,6 +2579,21 @@ static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
 #ifndef HIPAC_BN_A
 #define HIPAC_BN_A 128
 #endif
+#ifndef HIPAC_S2_WIDE
+#define HIPAC_S2_WIDE 1  // layers 3-4 entry convs on 256 x 256 tiles of 128 x 64 wave tiles (see launch_conv)
+#endif
+#ifndef HIPAC_S2_BM
+#define HIPAC_S2_BM 256
+#endif
+#ifndef HIPAC_S2_BN
+#define HIPAC_S2_BN 256
+#endif
+#ifndef HIPAC_S2_WTM
+#define HIPAC_S2_WTM 128
+#endif
+#ifndef HIPAC_S2_NSTAGE
+#define HIPAC_S2_NSTAGE 2
+#endif
 template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
@@ -2640,6 +2657,21 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);  // persistent; both are multiples of 8
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
                        n_mtiles, zero_page, (const T*)nullptr);
+  } else if constexpr (HIPAC_S2_WIDE && KS == 3 && STRIDE == 2 && !SPLIT && COUT % HIPAC_S2_BN == 0 && !RESID && !OUTF32) {
+    // plain 3x3 / stride 2 entry convs of layers 3-4 (their projection is folded into the block's second conv): one
+    // 8-wave workgroup per CU, every wave a 128 pixel x 64 channel tile -- 0.75 LDS fragment reads per MFMA instead of 1
+    // and half the LDS-DMA bytes per FLOP of the 128 x 128 tile
+    constexpr int BM = HIPAC_S2_BM, BN = HIPAC_S2_BN, NSTAGE = HIPAC_S2_NSTAGE, WTM = HIPAC_S2_WTM;
+    constexpr int THREADS = (BM / WTM) * (BN / 64) * 64;
+    constexpr int LDS = NSTAGE * (BM + BN) * 128;
+    auto kern = conv_glds_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BM, BN, NSTAGE, RELU, RESID, OUTF32, false, SPLIT, WTM>;
+    static bool attr_done[kMaxDevices] = {};
+    if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+    const int n_mtiles = (M + BM - 1) / BM;
+    const int mt8 = (n_mtiles + 7) / 8 * 8;
+    dim3 grid(mt8 * (COUT / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out,
+                       M, n_mtiles, zero_page, (const T*)nullptr, (const float*)nullptr, (void*)nullptr);
   } else {
     using C = TileCfg<COUT>;
     constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;

@@ -42,6 +42,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def active(group=None) -> bool:
+    """True when the collectives of this module have to run: a process group with more than one rank -- or with ONE rank
+    and ``HIPAC_DIST_FORCE=1`` (test hook: the one-GPU box has no second device for RCCL, so the single-rank nccl test
+    drives every exchange of the product path through RCCL itself instead of returning early)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("HIPAC_DIST_FORCE") == "1"
+
+
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
     """Slide i -> rank i mod world."""
     return list(range(rank, n_units, world))
@@ -60,7 +69,7 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather-v along dim 0 (ranks may hold different row counts): one int64 count
     exchange, then one all-gather on a max-padded buffer, trimmed and concatenated in
     rank order."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not active(group):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":  # gloo has no CUDA all_gather: stage through the host
         return all_gather_rows(t.cpu(), group).to(t.device)
@@ -82,7 +91,7 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
 def all_gather_equal(t: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather along dim 0 when every rank holds the SAME number of rows (the benchmark's equal patch
     shards): one collective into one preallocated tensor, no count exchange, no host synchronisation."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not active(group):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         return all_gather_equal(t.cpu(), group).to(t.device)
@@ -127,14 +136,14 @@ def score_sharded(n_units: int, score_fn, rank: Optional[int] = None, world: Opt
     if dev is None:  # a rank without units still takes part in the exchange (as many columns as the others, zero rows)
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     has_logits = torch.tensor([0 if n_cls is None else n_cls], dtype=torch.int64)
-    if world > 1:
+    if active(group):
         lst = [torch.zeros_like(has_logits) for _ in range(world)]
         dist.all_gather(lst, has_logits.to(dev) if dist.get_backend(group) == "nccl" else has_logits, group=group)
         n_cls = max(int(t.item()) for t in lst) or None
     feats = torch.cat(fs) if fs else torch.zeros((0, 512), dtype=torch.float32, device=dev)
     logits = (torch.cat(ls) if ls else torch.zeros((0, n_cls), dtype=torch.float32, device=dev)) if n_cls else None
     meta = torch.cat(ms) if ms else torch.zeros((0, 5), dtype=torch.int32, device=dev)
-    if world > 1:
+    if active(group):
         feats, logits, meta = gather_results(feats, logits, meta, group)
         order = torch.argsort(meta[:, 4], stable=True)
         feats, meta = feats[order], meta[order]
@@ -144,7 +153,7 @@ def score_sharded(n_units: int, score_fn, rank: Optional[int] = None, world: Opt
 
 def broadcast0(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place broadcast of rank 0's tensor (nn.DataParallel replicates the module of device 0 before every forward)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         if t.is_cuda and dist.get_backend(group) == "gloo":
             h = t.cpu()
             dist.broadcast(h, 0, group=group)
@@ -156,7 +165,7 @@ def broadcast0(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def all_reduce_sum_scalars(values: Sequence[float], device=None) -> List[float]:
     """Sum of a few host numbers over the ranks (loss and accuracy counters of the training loops)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return list(values)
     on_gpu = dist.get_backend() == "nccl"
     t = torch.tensor(list(values), dtype=torch.float64, device=device if on_gpu else "cpu")

@@ -105,7 +105,9 @@ class GradScaler:
                                                           self._flag.data_ptr(), capi._stream()), "hipac_grads_unscale_check")
         bad = float(self._flag.item())
         import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size() > 1:
+
+        from .dist import active
+        if active():
             t = torch.tensor([bad], dtype=torch.float32, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bad = float(t.item())
@@ -280,7 +282,8 @@ class NativeLinear:
 def _all_reduce_sum(t: torch.Tensor):
     import torch.distributed as dist
 
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    from .dist import active
+    if active():
         if t.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through the host
             h = t.cpu()
             dist.all_reduce(h)
@@ -293,9 +296,9 @@ def _all_gather_rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """(rows of every rank concatenated rank-major, first row of this rank); equal row counts per rank."""
     import torch.distributed as dist
 
-    from .dist import all_gather_equal
+    from .dist import active, all_gather_equal
 
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return t, 0
     return all_gather_equal(t), dist.get_rank() * t.shape[0]
 

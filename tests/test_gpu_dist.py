@@ -1,5 +1,5 @@
-"""Multi-rank paths on the GPU box (one MI355X: both ranks on cuda:0, gloo process group -- RCCL wants one GPU per rank
-and is first exercised by the driver's 8-GPU run): BASELINE configs[3] (slides sharded over the ranks, one ragged
+"""Multi-rank paths on the GPU box (one MI355X: both ranks on cuda:0, gloo process group -- RCCL wants one GPU per rank, so
+the 2-rank cases run over gloo and `test_single_rank_rccl_drives_every_exchange` sends the same exchanges through RCCL with one rank): BASELINE configs[3] (slides sharded over the ranks, one ragged
 all-gather), the product CLI's --world_size launcher, and the classifier step's global weighted cross-entropy."""
 import os
 import subprocess
@@ -148,3 +148,51 @@ def test_two_rank_classifier_step(tmp_path):
     # and it is NOT the per-rank-normalised sum the round-2 code computed (about world x larger)
     local = sum(F.cross_entropy(l.detach(), y[r], weight=w) for r, l in enumerate(logits))
     assert abs(float(local) - float(loss)) > 1e-3
+
+
+def test_single_rank_rccl_drives_every_exchange(tmp_path):
+    """RCCL on the hardware this box has: a one-rank "nccl" process group with HIPAC_DIST_FORCE=1, so that the slide-sharded
+    scan (count + padded all-gathers), the SimCLR step (all-gather of z, all-reduce of the gradients, MAX all-reduce of the
+    loss-scale flag), the rank-0 broadcast and the scalar all-reduce really call RCCL on device tensors.  With one rank every
+    collective is the identity, so the results must equal a process that has no process group -- bit for bit."""
+    specs = [[1500, 1300, 31], [1250, 1400, 32]]
+    torch.save(torch.tensor(specs), tmp_path / "specs.pt")
+    from ss25_hierarchical_multiscale_image_classification_amd import train_native as TN
+
+    from ss25_hierarchical_multiscale_image_classification_amd.simclr import SimCLRModel
+
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(5)
+    sd = {k: v.clone() for k, v in SimCLRModel().state_dict().items()}
+    x = torch.rand(2, 6, 3, 224, 224, generator=g)
+    torch.save(sd, tmp_path / "sd.pt")
+    torch.save(x, tmp_path / "x.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(HELPERS, "rccl_one_rank.py"), str(tmp_path), str(launch.free_port())],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(tmp_path / "rccl.pt", weights_only=True)
+
+    net = capi.PackedResNet18(synth.seeded_resnet18_state_dict(0, num_classes=2), precision="fp16x3")
+    fs, ls, ms = [], [], []
+    for i, (w, h, seed) in enumerate(specs):
+        slide = extract.DeviceSlide.synthetic(w, h, seed=seed, name=f"slide_{i}", with_polygons=True)
+        f, l, _, meta = extract.score_slide(slide, net, levels=(1, 2, 3), fwd_batch=64)
+        fs.append(f.cpu()), ls.append(l.cpu()), ms.append(meta.cpu())
+    sf, sl, sm = got["slides"]
+    assert sf.shape[0] > 0 and torch.equal(sf, torch.cat(fs)) and torch.equal(sl, torch.cat(ls))
+    assert torch.equal(sm[:, :4], torch.cat(ms)) and sm[:, 4].tolist() == sum(([i] * fs[i].shape[0] for i in range(2)), [])
+    assert torch.equal(got["eq"], sf[:7]) and got["scal"] == [1.5, 2.0, -3.25]
+    tr = TN.NativeSimCLRTrainer(sd, device="cuda:0", precision="fp16")
+    loss = tr.step(x[0].cuda().contiguous(), x[1].cuda().contiguous())
+    assert float(loss) == got["simclr"]["fp16"]["loss"]
+    mine = tr.state_dict()  # the mixed-precision step is deterministic (two-stage reductions, no atomics): bit for bit
+    assert set(mine) == set(got["simclr"]["fp16"]["params"])
+    for k, v in mine.items():
+        assert torch.equal(v.cpu(), got["simclr"]["fp16"]["params"][k]), k
+    tr = TN.NativeSimCLRTrainer(sd, device="cuda:0", precision="fp32")
+    loss = tr.forward_backward(x[0].cuda().contiguous(), x[1].cuda().contiguous())
+    assert abs(float(loss) - got["simclr"]["fp32"]["loss"]) <= 1e-6 * abs(float(loss))
+    for k, v in tr.grad_dict().items():  # fp32 reductions use atomics: equal to rounding
+        ref = got["simclr"]["fp32"]["grads"][k]
+        assert float((v.cpu() - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-12, k
