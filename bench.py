@@ -405,20 +405,6 @@ def run_resnet(args, rank, world, dev):
             rec["parity"] = parity_block(nets, u8_256, ref)
     del data
     torch.cuda.empty_cache()
-    if not args.no_simclr and world == 1 and rank == 0:
-        # configs[4], bounded: the native SimCLR step on 2 x 256 views, a few steps (the full 2 x 1024 is
-        # `--workload simclr`); same record as that workload, with its roofline
-        import argparse as _ap
-
-        from ss25_hierarchical_multiscale_image_classification_amd import train_native
-        try:
-            sargs = _ap.Namespace(simclr_views=256, warmup=1, steps=3, train_precision="fp32")
-            rec["simclr"] = train_native.bench_simclr_step(sargs, rank, world, dev)  # the reference's arithmetic for this loop
-            sargs.train_precision = "fp16"  # mixed precision (the reference's autocast arithmetic of the fine-tune loops)
-            rec["simclr"]["mixed_precision"] = train_native.bench_simclr_step(sargs, rank, world, dev)
-        except (RuntimeError, capi.HipacError) as e:
-            rec["simclr"] = {"error": str(e)[:300]}
-        torch.cuda.empty_cache()
     if not args.no_wsi:
         sides = [int(s) for s in args.wsi_sides.split(",") if s]
         if world > 1:
@@ -440,6 +426,39 @@ def run_resnet(args, rank, world, dev):
             if world == 1 and not args.no_cpu_baseline:
                 w["cpu_baseline"] = cpu_baseline_wsi()
             rec["wsi"] = w
+    if not args.no_simclr:
+        # configs[4], bounded: the native SimCLR step on 2 x 256 views over all ranks, a few steps (the full 2 x 1024 is
+        # `--workload simclr`); same record as that workload, with its roofline.  N > 1: data parallel -- all-gather of z,
+        # all-reduce of the gradients (RCCL) -- under a watchdog, so that a stuck collective costs this object, not the line
+        import argparse as _ap
+
+        from ss25_hierarchical_multiscale_image_classification_amd import train_native
+
+        def simclr_object():
+            torch.cuda.set_device(dev)
+            sargs = _ap.Namespace(simclr_views=256, warmup=1, steps=3, train_precision="fp32")
+            out = train_native.bench_simclr_step(sargs, rank, world, dev)  # the reference's arithmetic for this loop
+            sargs.train_precision = "fp16"  # mixed precision (the reference's autocast arithmetic of the fine-tune loops)
+            out["mixed_precision"] = train_native.bench_simclr_step(sargs, rank, world, dev)
+            return out
+
+        try:
+            if world == 1:
+                obj = simclr_object()
+            else:
+                import concurrent.futures as _cf
+
+                fut = _cf.ThreadPoolExecutor(1).submit(simclr_object)
+                try:
+                    obj = fut.result(timeout=args.simclr_timeout)
+                except _cf.TimeoutError:
+                    obj = {"error": f"no result within {args.simclr_timeout:.0f} s (a collective did not return)"}
+                    rec["_abandon_process_group"] = True  # main(): print the line and leave without the group's teardown
+        except (RuntimeError, capi.HipacError) as e:
+            obj = {"error": str(e)[:300]}
+        if rank == 0:
+            rec["simclr"] = obj
+        torch.cuda.empty_cache()
     return rec
 
 
@@ -553,6 +572,7 @@ def build_parser():
     ap.add_argument("--simclr_views", type=int, default=1024, help="simclr: images per view per step, over all ranks")
     ap.add_argument("--train_precision", choices=["fp32", "fp16"], default="fp32",
                     help="simclr workload: fp32 (the reference's loop) or fp16 mixed precision (autocast-style)")
+    ap.add_argument("--simclr_timeout", type=float, default=240.0, help="N > 1: seconds the bounded `simclr` object may take")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--one_device", action="store_true",
@@ -582,8 +602,12 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     run = {"resnet": run_resnet, "wsi": run_wsi, "simclr": run_simclr}[args.workload]
     rec = run(args, rank, world, dev)
+    abandon = bool(rec.pop("_abandon_process_group", False))
     if rank == 0:
         print(json.dumps(rec), flush=True)
+    if abandon:  # a collective is still stuck in a worker thread: the line is out, do not wait for the group
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

@@ -196,3 +196,24 @@ def test_single_rank_rccl_drives_every_exchange(tmp_path):
     for k, v in tr.grad_dict().items():  # fp32 reductions use atomics: equal to rounding
         ref = got["simclr"]["fp32"]["grads"][k]
         assert float((v.cpu() - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-12, k
+
+
+def test_bench_two_ranks_default_line(tmp_path):
+    """`bench.py --gpus 2` as the driver starts it (here: both ranks on cuda:0 over gloo): the parent launches two fresh
+    ranks, each runs the default workload on its own patches / slide / views, rank 0 prints ONE JSON line whose value is the
+    aggregate over both ranks and whose `wsi` and `simclr` objects come from the sharded runs."""
+    import json
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one_device", "--steps", "2",
+           "--warmup", "1", "--batch", "1024", "--no_cpu_baseline", "--wsi_sides", "3000", "--rank_timeout", "800"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert abs(rec["value"] - 2 * 1024 * 2 / (rec["ms_per_step"] * 2e-3)) <= 1e-6 * rec["value"]  # whole-job aggregate
+    assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
+    wsi = rec["wsi"]["3000x3000"]
+    assert "error" not in wsi and wsi["slides"] == 2 and wsi["n_gpus"] == 2 and wsi["s_per_slide"] > 0
+    assert rec["simclr"]["n_gpus"] == 2 and rec["simclr"]["value"] > 0 and rec["simclr"]["final_loss"] > 0
