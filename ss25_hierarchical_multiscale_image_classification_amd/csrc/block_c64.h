@@ -67,7 +67,7 @@ __device__ __forceinline__ void c64_strip_mfma(const typename Elem<T>::frag (&wr
   }
   auto rd_step = [&](auto S) {
     constexpr int st = decltype(S)::value;
-    constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
+    constexpr int kh = c64_step_kh(st), kw = c64_step_kw(st), kk = c64_step_kk(st);
 #pragma unroll
     for (int i = 0; i < NSUB; ++i)
       ring[st % (PF + 1)][i] = *(const __attribute__((address_space(3))) frag*)(size_t)(unsigned)((lb[i][kw] ^ (kk << 5)) + kh * PITCH);
@@ -83,7 +83,94 @@ __device__ __forceinline__ void c64_strip_mfma(const typename Elem<T>::frag (&wr
     constexpr int st = decltype(S)::value;
     if constexpr (st + PF < 36) rd_step(std::integral_constant<int, st + PF>{});
 #pragma unroll
-    for (int i = 0; i < NSUB; ++i) acc[i] = E::mfma(wreg[st / 4][st % 4], ring[st % (PF + 1)][i], acc[i]);
+    for (int i = 0; i < NSUB; ++i)
+      acc[i] = E::mfma(wreg[3 * c64_step_kh(st) + c64_step_kw(st)][c64_step_kk(st)], ring[st % (PF + 1)][i], acc[i]);
+    __builtin_amdgcn_sched_barrier(0);  // pin the read-ahead
+  });
+#if HIPAC_BLK_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+// Fragment-sharing form of the loop above (-DHIPAC_BLK_SHARE=1 -DHIPAC_C64_ORDER=1; OFF by default: measured slower, see the
+// end of this comment): LDS serves 40 fragment reads per 72 MFMAs instead of 72.
+//   * rows: the window rows of a wave's sub-tiles overlap -- sub-tile i, tap row kh reads row pair R = y0 + 2i + kh -- so
+//     the loop walks the DISTINCT row pairs rho = 0 .. 2 NSUB and feeds every (sub-tile, kh) that reads that pair
+//     (rho = 2: sub-tile 0's kh = 2 and sub-tile 1's kh = 0);
+//   * columns: a 16-lane DPP row is 16 consecutive window columns of one (row, k-half), so of the three tap columns
+//     only two are read -- A = columns lx, B = columns lx + 2 -- and kw = 1 (columns lx + 1) is A shifted down one lane
+//     (row_shl:1; lane 15 has no source and keeps its old value) overwritten by B shifted up one lane (row_shr:1; lane 0
+//     has no source and keeps A's column 1): 8 v_mov_dpp instead of a 1 KB LDS read.
+// Every accumulator still sees its taps in the order kh = 0, 1, 2; within a tap row the order is (k16 step, kw) instead
+// of (kw, k16 step) -- conv3x3_c64_kernel uses the same order (HIPAC_C64_ORDER), so fused == unfused stays bit for bit.
+// Measured on one box (tools/l1bench.py, ns per patch and block): 514 as above (72 reads), 527 with rows + columns shared (40
+// reads, but three dependent MFMAs in a row on one accumulator where the plain loop alternates two), 540 with the columns
+// shared only (48 reads, accumulators alternating): the v_mov_dpp feeding an MFMA operand cost more than the LDS reads they
+// replace -- layer1 is not bound by its fragment reads.
+#ifndef HIPAC_BLK_SHARE
+#define HIPAC_BLK_SHARE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename F>
+__device__ __forceinline__ F frag_mid_column(const F& a, const F& b) {
+  u32x4 A = __builtin_bit_cast(u32x4, a), B = __builtin_bit_cast(u32x4, b), S;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = __builtin_amdgcn_update_dpp((int)A[e], (int)A[e], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+    S[e] = (unsigned)__builtin_amdgcn_update_dpp(t, (int)B[e], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  }
+  return __builtin_bit_cast(F, S);
+}
+#else
+template <typename F>
+__device__ inline F frag_mid_column(const F& a, const F&) { return a; }
+#endif
+
+template <typename T, int NSUB, int PITCH>
+__device__ __forceinline__ void c64_strip_mfma_share(const typename Elem<T>::frag (&wreg)[9][4], const int (&lb)[NSUB][3],
+                                                     const float* __restrict__ bl, f32x16 (&acc)[NSUB]) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int PF = HIPAC_BLK_PF;
+  constexpr int NRHO = 2 * NSUB + 1, NST = 4 * NRHO;  // distinct row pairs; steps = (row pair, k16 step)
+  frag ra[PF + 1], rb[PF + 1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = b[e];
+  }
+  auto rd_step = [&](auto S) {
+    constexpr int st = decltype(S)::value;
+    constexpr int rho = st / 4, kk = st % 4;
+    // row pair rho through the window of the sub-tile that owns it (each window is contiguous in the ring on its own)
+    constexpr int i = rho <= 2 ? 0 : (rho - 1) / 2, row = rho - 2 * i;
+    ra[st % (PF + 1)] = *(const __attribute__((address_space(3))) frag*)(size_t)(unsigned)((lb[i][0] ^ (kk << 5)) + row * PITCH);
+    rb[st % (PF + 1)] = *(const __attribute__((address_space(3))) frag*)(size_t)(unsigned)((lb[i][2] ^ (kk << 5)) + row * PITCH);
+  };
+#if HIPAC_BLK_PRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
+#if HIPAC_BLK_ABL & 16
+  return;
+#endif
+  static_for<PF>([&](auto S) { rd_step(S); });
+  static_for<NST>([&](auto S) {
+    constexpr int st = decltype(S)::value;
+    constexpr int rho = st / 4, kk = st % 4;
+    if constexpr (st + PF < NST) rd_step(std::integral_constant<int, st + PF>{});
+    const frag fa = ra[st % (PF + 1)], fb = rb[st % (PF + 1)];
+    const frag fm = frag_mid_column(fa, fb);
+    static_for<NSUB>([&](auto I) {
+      constexpr int i = decltype(I)::value, kh = rho - 2 * i;
+      if constexpr (kh >= 0 && kh < 3) {
+        acc[i] = E::mfma(wreg[3 * kh + 0][kk], fa, acc[i]);
+        acc[i] = E::mfma(wreg[3 * kh + 1][kk], fm, acc[i]);
+        acc[i] = E::mfma(wreg[3 * kh + 2][kk], fb, acc[i]);
+      }
+    });
     __builtin_amdgcn_sched_barrier(0);  // pin the read-ahead
   });
 #if HIPAC_BLK_PRIO
@@ -100,6 +187,12 @@ __device__ __forceinline__ unsigned relu_pk(unsigned v) {
 
 #ifdef HIPAC_HALO_STAMPS
 static __device__ unsigned long long g_blk_stamps[4];  // barrier cycles (A, B), wave-steps (A, B)
+#endif
+#if HIPAC_BLK_SHARE
+static_assert(HIPAC_C64_ORDER == 1, "the fragment-sharing loop accumulates in (kh, k16 step, kw) order");
+#define C64_STRIP_MFMA c64_strip_mfma_share
+#else
+#define C64_STRIP_MFMA c64_strip_mfma
 #endif
 constexpr int kBlkRing = 30;              // ring rows (rows 30, 31 of each buffer repeat L = 30, 31)
 constexpr int kBlkXPitch = 18 * 128;      // x ring: 18 columns x 64 channels
@@ -307,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void block_c64_kernel(const T* __restrict__
           for (int kw = 0; kw < 3; ++kw) lb[i][kw] = la[kw] + wbase;
         }
         HALO_STAMP(a_t1);
-        c64_strip_mfma<T, 2, XP>(wreg, lb, bl, acc);
+        C64_STRIP_MFMA<T, 2, XP>(wreg, lb, bl, acc);
         HALO_STAMP(a_t2);
 #if HIPAC_BLK_ABL & 2
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
@@ -376,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void block_c64_kernel(const T* __restrict__
             for (int kw = 0; kw < 3; ++kw) lb[i][kw] = la[kw] + wbase;
           }
           HALO_STAMP(b_t2);
-          c64_strip_mfma<T, 2, IP>(wreg, lb, bl, acc);
+          C64_STRIP_MFMA<T, 2, IP>(wreg, lb, bl, acc);
 #ifdef HIPAC_HALO_STAMPS
           HALO_STAMP(b_t3);
           z_sum[5] += b_t3 - b_t2, z_sum[7] += b_t2 - b_t1;
@@ -390,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void block_c64_kernel(const T* __restrict__
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) lb[0][kw] = la[kw] + wbase;
           f32x16(&acc1)[1] = reinterpret_cast<f32x16(&)[1]>(acc[0]);
-          c64_strip_mfma<T, 1, IP>(wreg, lb, bl, acc1);
+          C64_STRIP_MFMA<T, 1, IP>(wreg, lb, bl, acc1);
           pend_n = 1, pend_y = ys, pend_sl = has_pair ? 2 : 0;
         }
       }

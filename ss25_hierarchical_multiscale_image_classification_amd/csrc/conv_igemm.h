@@ -628,6 +628,16 @@ static __device__ unsigned long long g_halo_stamps[8];
 #ifndef HIPAC_C64_PF
 #define HIPAC_C64_PF 2  // layer1 kernel: LDS fragment reads run this many k16 steps ahead of their MFMAs
 #endif
+// order of the 36 (tap, k16) steps of a 3x3 x 64-channel accumulation, shared by conv3x3_c64_kernel and the fused block
+// (their results are compared bit for bit): 0 = (kh, kw, k16 step), the default; 1 = (kh, k16 step, kw), what the fragment-sharing
+// experiment of block_c64.h (HIPAC_BLK_SHARE) needs
+#ifndef HIPAC_C64_ORDER
+#define HIPAC_C64_ORDER 0
+#endif
+constexpr int c64_step_kh(int st) { return st / 12; }
+constexpr int c64_step_kw(int st) { return HIPAC_C64_ORDER ? st % 3 : (st % 12) / 4; }
+constexpr int c64_step_kk(int st) { return HIPAC_C64_ORDER ? (st % 12) / 3 : st % 4; }
+
 #ifndef HIPAC_HALO_TAP_UNROLL
 #define HIPAC_HALO_TAP_UNROLL 3  // taps per unrolled group: 3 makes kw a constant (9 is slower: 2x, code size)
 #endif
@@ -2162,7 +2172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
     const unsigned char* const Hb = Hl + ((ly0 * HALO + lx) << 7);
     auto rd_step = [&](auto S) {
       constexpr int st = decltype(S)::value;
-      constexpr int tap = st / 4, kk = st % 4, kh = tap / 3, kw = tap % 3;
+      constexpr int kh = c64_step_kh(st), kw = c64_step_kw(st), kk = c64_step_kk(st);
       const unsigned char* const ptr = Hb + (ax[kw] | (by[kh] ^ (kk << 5)));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -2173,7 +2183,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
       constexpr int st = decltype(S)::value;
       if constexpr (st + PF < 36) rd_step(std::integral_constant<int, st + PF>{});
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = E::mfma(wreg[st / 4][st % 4], ring[st % (PF + 1)][i], acc[i]);
+      for (int i = 0; i < 2; ++i)
+        acc[i] = E::mfma(wreg[3 * c64_step_kh(st) + c64_step_kw(st)][c64_step_kk(st)], ring[st % (PF + 1)][i], acc[i]);
       __builtin_amdgcn_sched_barrier(0);  // pin the read-ahead: the scheduler otherwise folds it back to one step
     });
     __builtin_amdgcn_s_setprio(0);
