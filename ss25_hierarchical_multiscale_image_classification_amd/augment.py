@@ -1,0 +1,271 @@
+"""SimCLR's input pipeline with the patches resident in HBM and the augmentation on the device.
+
+The reference (src/models/simclr.py:57-83) reads PNG patches through ``PatchDataset(transform=None)``, wraps them in
+``SimCLRDataset(base, get_simclr_transform())`` and lets DataLoader workers run the torchvision / Pillow transforms per
+sample, twice per patch.  Here the decoded patches live once in HBM (``DevicePatchPool``: uint8 [N, P, P, 3]) and a step's
+two views are produced by ``hipac_augment_views`` (csrc/augment.hip: Pillow's arithmetic, bit-exact).  What stays on the
+host is the random DRAWING: ``draw_simclr_view`` takes the draws of ``transforms.simclr_transform()`` in the same order from
+the same generators (torch's global generator for crop / jitter / grayscale, ``random`` for the flip), so that with equal
+seeds the host pipeline and this one see the same parameters -- which is how tests/test_gpu_augment.py compares them.
+"""
+from __future__ import annotations
+
+import math
+import random
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from .transforms import RandomResizedCrop
+
+PARAMS = 16  # int32 per view (include/hipac.h, hipac_augment_views)
+OUT = 224
+
+
+def _f32_bits(x: float) -> int:
+    return int(np.float32(x).view(np.int32))
+
+
+def draw_simclr_view(index: int, width: int, height: int, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0),
+                     jitter=(0.4, 0.4, 0.4, 0.1), p_jitter: float = 0.8, p_gray: float = 0.2, p_flip: float = 0.5) -> List[int]:
+    """The 16 parameters of one view: the draws of RandomResizedCrop.get_params, RandomHorizontalFlip, RandomApply,
+    ColorJitter (randperm(4), then brightness / contrast / saturation / hue) and RandomGrayscale, in that order
+    (src/models/simclr.py:58-62; transforms.py restates the torchvision classes)."""
+    top, left, h, w = RandomResizedCrop.get_params(width, height, scale, ratio)
+    flip = 1 if random.random() < p_flip else 0
+    ops = [-1, -1, -1, -1]
+    b = c = s = 1.0
+    hue = 0
+    if not (p_jitter < float(torch.rand(1).item())):
+        ops = torch.randperm(4).tolist()
+        draw = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi).item())
+        b = draw(max(0.0, 1.0 - jitter[0]), 1.0 + jitter[0])
+        c = draw(max(0.0, 1.0 - jitter[1]), 1.0 + jitter[1])
+        s = draw(max(0.0, 1.0 - jitter[2]), 1.0 + jitter[2])
+        hue = int(draw(-jitter[3], jitter[3]) * 255) & 0xFF  # adjust_hue: np.uint8(int(hue_factor * 255))
+    gray = 1 if float(torch.rand(1).item()) < p_gray else 0
+    return [index, top, left, h, w, flip, *ops, gray, _f32_bits(b), _f32_bits(c), _f32_bits(s), hue, 0]
+
+
+def draw_simclr_batch(indices: Sequence[int], P: int, rng: np.random.Generator, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0),
+                      jitter=(0.4, 0.4, 0.4, 0.1), p_jitter: float = 0.8, p_gray: float = 0.2, p_flip: float = 0.5) -> np.ndarray:
+    """The same distributions as ``draw_simclr_view`` for a whole batch at once (numpy generator; per view the Python
+    version costs ~0.1 ms of host time, i.e. more than the training step at 2 x 1024 views).  int32 [len(indices), 16]."""
+    n = len(indices)
+    out = np.zeros((n, PARAMS), np.int32)
+    out[:, 0] = np.asarray(indices, np.int32)
+    area = float(P) * P
+    # RandomResizedCrop.get_params: the first of 10 attempts that fits, else the whole (square) patch
+    target = area * rng.uniform(scale[0], scale[1], (n, 10))
+    ar = np.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1]), (n, 10)))
+    w = np.rint(np.sqrt(target * ar)).astype(np.int64)
+    h = np.rint(np.sqrt(target / ar)).astype(np.int64)
+    ok = (w > 0) & (w <= P) & (h > 0) & (h <= P)
+    first = np.where(ok.any(1), ok.argmax(1), 0)
+    rows = np.arange(n)
+    hh = np.where(ok.any(1), h[rows, first], P)
+    ww = np.where(ok.any(1), w[rows, first], P)
+    top = np.floor(rng.random(n) * (P - hh + 1)).astype(np.int64)
+    left = np.floor(rng.random(n) * (P - ww + 1)).astype(np.int64)
+    top, left = np.where(ok.any(1), top, 0), np.where(ok.any(1), left, 0)
+    out[:, 1], out[:, 2], out[:, 3], out[:, 4] = top, left, hh, ww
+    out[:, 5] = rng.random(n) < p_flip
+    apply = rng.random(n) <= p_jitter
+    perm = np.argsort(rng.random((n, 4)), axis=1).astype(np.int32)
+    out[:, 6:10] = np.where(apply[:, None], perm, -1)
+    fac = lambda j: np.where(apply, rng.uniform(max(0.0, 1.0 - jitter[j]), 1.0 + jitter[j], n), 1.0).astype(np.float32)
+    out[:, 11], out[:, 12], out[:, 13] = fac(0).view(np.int32), fac(1).view(np.int32), fac(2).view(np.int32)
+    hue = (rng.uniform(-jitter[3], jitter[3], n) * 255).astype(np.int64) & 0xFF  # int() truncates toward zero, as astype does
+    out[:, 14] = np.where(apply, hue, 0)
+    out[:, 10] = rng.random(n) < p_gray
+    return out
+
+
+class DevicePatchPool:
+    """uint8 [N, P, P, 3] patches in HBM + the resampling tables of every crop size 1..P -> 224."""
+
+    def __init__(self, patches: torch.Tensor, labels: Optional[Sequence[int]] = None):
+        if patches.dtype != torch.uint8 or patches.dim() != 4 or patches.shape[3] != 3 or patches.shape[1] != patches.shape[2]:
+            raise capi.HipacError("DevicePatchPool: patches must be uint8 [N, P, P, 3]")
+        if not patches.is_cuda:
+            raise capi.HipacError("DevicePatchPool: the pool lives in HBM (no CPU fallback)")
+        self.patches = patches.contiguous()
+        self.n, self.P = int(patches.shape[0]), int(patches.shape[1])
+        self.labels = None if labels is None else [int(v) for v in labels]
+        self.device = patches.device
+        per = [capi.resample_coeffs(size, OUT) for size in range(1, self.P + 1)]
+        self.ksize = max(k for _, _, k in per)
+        tb = np.zeros((self.P, OUT, 2), np.int32)
+        tk = np.zeros((self.P, OUT, self.ksize), np.int32)
+        for i, (bounds, kk, k) in enumerate(per):
+            tb[i], tk[i, :, :k] = bounds, kk
+        self.tab_bounds = torch.from_numpy(tb).to(self.device)
+        self.tab_kk = torch.from_numpy(tk).to(self.device)
+        self.lut = torch.from_numpy(capi.normalize_lut()).to(self.device)
+        self._scratch = {}
+
+    def __len__(self):
+        return self.n
+
+    @classmethod
+    def from_patch_dataset(cls, base, device="cuda", workers: int = 16) -> "DevicePatchPool":
+        """Decode every PNG of a ``PatchDataset(transform=None)`` once (host threads) and keep the pixels in HBM."""
+        from PIL import Image
+
+        paths = list(base.image_paths)
+
+        def load(p):
+            with Image.open(p) as im:
+                return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+        with ThreadPoolExecutor(max(1, workers)) as ex:
+            arrs = list(ex.map(load, paths))
+        if not arrs:
+            raise capi.HipacError("DevicePatchPool: the dataset holds no patches")
+        shp = arrs[0].shape
+        if shp[0] != shp[1] or any(a.shape != shp for a in arrs):
+            raise capi.HipacError("DevicePatchPool: patches of one pool must share one square size (one level directory)")
+        dev = torch.device(device)
+        pool = torch.empty((len(arrs),) + shp, dtype=torch.uint8, device=dev)
+        step = max(1, (256 << 20) // (shp[0] * shp[1] * 3))
+        for i in range(0, len(arrs), step):
+            pool[i:i + step] = torch.from_numpy(np.stack(arrs[i:i + step])).to(dev)
+        return cls(pool, labels=list(getattr(base, "labels", [])) or None)
+
+    def _buffers(self, n_views: int):
+        key = n_views
+        if key not in self._scratch:
+            dev = self.device
+            self._scratch = {key: (torch.empty((n_views, PARAMS), dtype=torch.int32, device=dev),
+                                   torch.empty((n_views, self.P, OUT, 3), dtype=torch.uint8, device=dev),
+                                   torch.empty((n_views, OUT, OUT, 3), dtype=torch.uint8, device=dev))}
+        return self._scratch[key]
+
+    def augment(self, params: np.ndarray, want_u8: bool = False, want_float: bool = True):
+        """params int32 [n_views, 16] (host) -> float32 [n_views, 3, 224, 224] on the device (and / or the uint8
+        [n_views, 224, 224, 3] image before ToTensor)."""
+        params = np.ascontiguousarray(params, dtype=np.int32)
+        if params.ndim != 2 or params.shape[1] != PARAMS:
+            raise capi.HipacError("augment: params must be int32 [n_views, 16]")
+        n = params.shape[0]
+        pdev, tmp, crops = self._buffers(n)
+        # the parameters travel through a ring of PINNED host buffers: an asynchronous copy from pageable memory would make the
+        # host wait for everything queued before it (the previous training step), and the pinned buffer must stay untouched
+        # until its copy has run -- an event per slot says when
+        slot = self._pin_next = (getattr(self, "_pin_next", -1) + 1) % 4
+        ring = self.__dict__.setdefault("_pin", [None] * 4)
+        evs = self.__dict__.setdefault("_pin_ev", [None] * 4)
+        if ring[slot] is None or ring[slot].shape[0] < n:
+            ring[slot] = torch.empty((n, PARAMS), dtype=torch.int32).pin_memory()
+        if evs[slot] is not None:
+            evs[slot].synchronize()
+        host = ring[slot][:n]
+        host.numpy()[:] = params
+        out = torch.empty((n, 3, OUT, OUT), dtype=torch.float32, device=self.device) if want_float else None
+        out_u8 = torch.empty((n, OUT, OUT, 3), dtype=torch.uint8, device=self.device) if want_u8 else None
+        lib = capi.load_library()
+        with torch.cuda.device(self.device):
+            capi._check(lib.hipac_augment_views(self.patches.data_ptr(), self.n, self.P, host.data_ptr(), pdev.data_ptr(), n,
+                                                self.tab_bounds.data_ptr(), self.tab_kk.data_ptr(), self.ksize, self.lut.data_ptr(),
+                                                tmp.data_ptr(), crops.data_ptr(), out.data_ptr() if out is not None else None,
+                                                out_u8.data_ptr() if out_u8 is not None else None, capi._stream()),
+                        "hipac_augment_views")
+            evs[slot] = torch.cuda.Event()
+            evs[slot].record(torch.cuda.current_stream(self.device))
+        return (out, out_u8) if want_u8 else out
+
+
+class DeviceSimCLRLoader:
+    """Batches of (x_i, x_j) view pairs, float32 [B, 3, 224, 224] each, made on the device: what
+    ``DataLoader(SimCLRDataset(base, get_simclr_transform()), batch_size, shuffle=True)`` yields
+    (src/models/simclr.py:70-73).  ``indices_of(epoch)`` may be overridden by a sampler (rank shares)."""
+
+    def __init__(self, pool: DevicePatchPool, batch_size: int, shuffle: bool = True, seed: int = 0, rank: int = 0, world: int = 1,
+                 drop_last: bool = False, mirror_host_draws: bool = False):
+        """``mirror_host_draws``: take every view's parameters with ``draw_simclr_view`` from torch's / random's global
+        generators (the host transforms' own draw order; tests), instead of the batched numpy draws."""
+        self.pool, self.batch_size, self.shuffle, self.seed = pool, int(batch_size), shuffle, seed
+        self.rank, self.world, self.drop_last, self.epoch = rank, world, drop_last, 0
+        self.mirror_host_draws = mirror_host_draws
+        self._rng = np.random.default_rng([seed, rank])
+
+    def __len__(self):
+        n = len(self.pool)
+        return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
+
+    def _batches(self) -> Iterator[List[int]]:
+        n = len(self.pool)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        for i in range(0, n, self.batch_size):
+            b = order[i:i + self.batch_size]
+            if len(b) < self.batch_size and self.drop_last:
+                return
+            if self.world > 1:  # this rank's contiguous share of the global batch, equal on all ranks (dist.RankBatchSampler)
+                per = len(b) // self.world
+                b = b[self.rank * per:(self.rank + 1) * per]
+            if b:
+                yield b
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        P = self.pool.P
+        for b in self._batches():
+            # view i then view j of every sample, as SimCLRDataset.__getitem__ draws them (src/datasets/simclr_dataset.py:10-11)
+            rows = np.empty((2, len(b), PARAMS), np.int32)
+            if self.mirror_host_draws:
+                for k, idx in enumerate(b):
+                    rows[0, k] = draw_simclr_view(idx, P, P)
+                    rows[1, k] = draw_simclr_view(idx, P, P)
+            else:
+                rows[0], rows[1] = draw_simclr_batch(b, P, self._rng), draw_simclr_batch(b, P, self._rng)
+            x = self.pool.augment(rows.reshape(-1, PARAMS))
+            yield x[:len(b)], x[len(b):]
+        self.epoch += 1
+
+
+def bench_input_pipeline(n_pairs: int = 256, P: int = 224, steps: int = 5, host_views: int = 48, device="cuda") -> dict:
+    """bench.py's ``simclr.input_pipeline``: view pairs per second of the device pipeline (batched draws + hipac_augment_views,
+    wall clock around ``steps`` batches) next to the host transforms (Pillow, one thread, ``host_views`` views)."""
+    import time
+
+    from PIL import Image
+
+    from . import synth, transforms
+
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(5)
+    pool = DevicePatchPool(torch.randint(0, 256, (max(n_pairs, 8), P, P, 3), generator=g, device=dev, dtype=torch.uint8))
+    loader = DeviceSimCLRLoader(pool, n_pairs, seed=1)
+    for _ in loader:  # warm-up epoch: tables, scratch, pinned ring
+        break
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for x_i, x_j in loader:
+            pass
+    torch.cuda.synchronize(dev)
+    n_batches = steps * len(loader)
+    dt = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        draw_simclr_batch(list(range(n_pairs)), P, rng)
+    t_draw = (time.perf_counter() - t1) / 20
+    T = transforms.simclr_transform()
+    img = Image.fromarray(pool.patches[0].cpu().numpy(), "RGB")
+    t2 = time.perf_counter()
+    for _ in range(host_views):
+        T(img)
+    t_host = (time.perf_counter() - t2) / host_views
+    return {"patch": P, "pairs_per_batch": n_pairs, "device_pairs_per_s": n_batches * min(n_pairs, len(pool)) / dt,
+            "host_draws_ms_per_batch": t_draw * 1e3,
+            "host_pillow_pairs_per_s_one_thread": 0.5 / t_host,
+            "note": "device: batched numpy draws + hipac_augment_views (crop/resize, flip, ColorJitter, grayscale, normalise; "
+                    "bit-exact vs Pillow); host: transforms.simclr_transform() = the reference's torchvision pipeline on Pillow, "
+                    "PNG decoding not included on either side"}

@@ -76,6 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--train_precision", choices=["fp16", "fp32"], default="fp16",
                    help="arithmetic of the classifier training step: fp16 = the reference's autocast + GradScaler "
                         "(src/main.py:499-508), fp32 = exact f32 MFMA")
+    p.add_argument("--device_aug", action="store_true",
+                   help="SimCLR pre-training: keep the decoded patches in HBM and make both views of a step on the device "
+                        "(hipac_augment_views) instead of in DataLoader workers")
     p.add_argument("--simclr_precision", choices=["fp16", "fp32"], default="fp32",
                    help="arithmetic of the SimCLR pre-training step (the reference's loop is fp32, src/models/simclr.py:85-96)")
     p.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
@@ -228,7 +231,8 @@ def cmd_train(args, strategy: Optional[str]):
         return 1
     train_resnet_classifier(patch_dir, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size,
                             precision=args.precision, simclr_epochs=args.simclr_epochs, max_steps=args.max_steps,
-                            train_precision=args.train_precision, simclr_precision=args.simclr_precision)
+                            train_precision=args.train_precision, simclr_precision=args.simclr_precision,
+                            device_aug=args.device_aug)
     return 0
 
 

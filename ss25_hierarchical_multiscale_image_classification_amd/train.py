@@ -82,7 +82,7 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
                             batch_size: int = 512, precision: str = "bf16", lr: float = 1e-4,
                             save_path: Optional[str] = None, device: str = "cuda", simclr_epochs: int = 200,
                             simclr_path: str = "simclr_encoder.pth", max_steps: Optional[int] = None,
-                            train_precision: str = "fp16", simclr_precision: str = "fp32"):
+                            train_precision: str = "fp16", simclr_precision: str = "fp32", device_aug: bool = False):
     """``train_resnet_classifier`` (strategy None, 30 epochs, src/main.py:472-534) and
     ``train_resnet_classifier_strategic`` (5 epochs, :536-606).  The training step runs on the native kernels
     (``train_native.NativeClassifierTrainer``) in ``train_precision``: "fp16" (default) = the reference's
@@ -107,7 +107,7 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
             # the final checkpoint goes to simclr_path itself, whatever its basename
             pretrain_simclr(patch_dir, epochs=simclr_epochs, batch_size=batch_size, device=device,
                             out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps, final_path=simclr_path,
-                            precision=simclr_precision)
+                            precision=simclr_precision, device_aug=device_aug)
             if world > 1:
                 torch.distributed.barrier()  # rank 0 wrote the file
         if not os.path.exists(simclr_path):

@@ -178,3 +178,31 @@ def test_trace_span_is_a_no_op_without_the_env_and_balanced_with_it(monkeypatch)
     except ValueError:
         pass
     assert calls == [("push", b"window decisions"), ("pop",)]
+
+
+def test_device_view_parameters_take_the_host_transforms_draws():
+    """augment.draw_simclr_view draws what transforms.simclr_transform() draws, in the same order from the same generators:
+    after one image both RNGs are in the same state, and the crop / flip it reports are the ones the host pipeline used."""
+    import random
+
+    from PIL import Image
+
+    from ss25_hierarchical_multiscale_image_classification_amd import augment, transforms
+
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (448, 448, 3), dtype=np.uint8), "RGB")
+    T = transforms.simclr_transform()
+    for seed in range(12):
+        torch.manual_seed(seed), random.seed(seed)
+        T(img)
+        st_t, st_r = torch.get_rng_state(), random.getstate()
+        torch.manual_seed(seed), random.seed(seed)
+        row = augment.draw_simclr_view(7, 448, 448)
+        assert torch.equal(torch.get_rng_state(), st_t) and random.getstate() == st_r
+        torch.manual_seed(seed), random.seed(seed)
+        top, left, h, w = transforms.RandomResizedCrop.get_params(448, 448, (0.08, 1.0), (3.0 / 4.0, 4.0 / 3.0))
+        assert row[:5] == [7, top, left, h, w] and row[5] == (1 if random.random() < 0.5 else 0)
+        assert len(row) == augment.PARAMS and row[15] == 0 and all(-1 <= o <= 3 for o in row[6:10])
+        if row[6] >= 0:
+            assert sorted(row[6:10]) == [0, 1, 2, 3]
+            b, c, s = (float(np.int32(v).view(np.float32)) for v in row[11:14])
+            assert 0.6 <= b <= 1.4 and 0.6 <= c <= 1.4 and 0.6 <= s <= 1.4 and (row[14] <= 25 or row[14] >= 231)
