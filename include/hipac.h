@@ -339,29 +339,34 @@ int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, i
 /* grads[i] *= inv_scale; found_inf[0] (device int32, zeroed by the caller) becomes 1 when a gradient is inf / nan. */
 int hipac_grads_unscale_check(float* grads, int64_t n, float inv_scale, int32_t* found_inf, void* stream);
 
-/* SimCLR view augmentation on patches resident in HBM -- replaces, per view, torchvision's PIL pipeline
- *   RandomResizedCrop(224) / RandomHorizontalFlip / RandomApply([ColorJitter(.4,.4,.4,.1)], .8) / RandomGrayscale(.2) /
- *   ToTensor / Normalize                                     src/models/simclr.py:57-66, applied twice per patch by
- *   SimCLRDataset.__getitem__                                src/datasets/simclr_dataset.py:8-12
+/* Training-view augmentation on patches resident in HBM -- replaces, per view, torchvision's PIL pipelines
+ *   geometry 0 (SimCLR): RandomResizedCrop(224) / RandomHorizontalFlip / RandomApply([ColorJitter(.4,.4,.4,.1)], .8) /
+ *     RandomGrayscale(.2) / ToTensor / Normalize               src/models/simclr.py:57-66, applied twice per patch by
+ *     SimCLRDataset.__getitem__                                src/datasets/simclr_dataset.py:8-12
+ *   geometry 1 (classifier loops, tumour patches; P must be 224): RandomHorizontalFlip / RandomVerticalFlip /
+ *     RandomRotation(90) / ColorJitter(.2,.2,.2,.1) / Resize((224,224)) / ToTensor / Normalize      src/main.py:417-425
+ *     (all-default parameters = the eval transform of :426-430 on a 224-pixel patch)
  * The random draws are the caller's (HOST memory, checked here); the kernels are Pillow's arithmetic (ImagingResample 8-bit
- * passes, ImagingBlend, the L conversion, rgb2hsv / hsv2rgb), bit-exact against Pillow.
+ * passes, affine_fixed nearest-neighbour rotation, ImagingBlend, the L conversion, rgb2hsv / hsv2rgb), bit-exact against Pillow.
  *   pool       : DEVICE uint8[n_pool][P][P][3] decoded patches
- *   params_host: HOST int32[n_views][16] per view:
- *                 [0] patch index  [1] crop top  [2] crop left  [3] crop height  [4] crop width  [5] horizontal flip
+ *   params_host: HOST int32[n_views][24] per view:
+ *                 [0] patch index  [1] crop top  [2] crop left  [3] crop height  [4] crop width (geometry 0)  [5] horizontal flip
  *                 [6..9] colour operations in application order (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none)
  *                 [10] grayscale  [11] brightness  [12] contrast  [13] saturation factor (float32 bit patterns)
- *                 [14] hue shift added to Pillow's uint8 H channel (0..255)  [15] reserved (0)
- *   params_dev : DEVICE int32[n_views][16] scratch (the checked copy the kernels read)
+ *                 [14] hue shift added to Pillow's uint8 H channel (0..255)  [15] reserved (0)  [16] vertical flip (geometry 1)
+ *                 [17..22] a0 a1 a2 a3 a4 a5 of affine_fixed (16.16): source x = (a2 + x a0 + y a1) >> 16,
+ *                 y = (a5 + x a3 + y a4) >> 16 (geometry 1; identity = 65536 0 0 0 65536 0)  [23] reserved (0)
+ *   params_dev : DEVICE int32[n_views][24] scratch (the checked copy the kernels read)
  *   tab_bounds : DEVICE int32[P][224][2], tab_kk DEVICE int32[P][224][ksize]: hipac_resample_coeffs(size, 224) for every
- *                source size 1..P (row size-1), taps beyond a row's count zero
+ *                source size 1..P (row size-1), taps beyond a row's count zero (geometry 0; may be NULL for geometry 1)
  *   lut        : DEVICE float32[3][256] = (v/255 - mean_c)/std_c in fp32
- *   tmp        : DEVICE uint8[n_views][P][224][3], crops: DEVICE uint8[n_views][224][224][3] (scratch)
+ *   tmp        : DEVICE uint8[n_views][P][224][3] (geometry 0), crops: DEVICE uint8[n_views][224][224][3] (scratch)
  *   out        : DEVICE float32[n_views][3][224][224] (NCHW, what the training step takes) or NULL
  *   out_u8     : DEVICE uint8[n_views][224][224][3] augmented image before ToTensor, or NULL (test tap)
  * n_views <= 65535. */
-int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, const int32_t* params_host, int32_t* params_dev, int n_views,
-                        const int32_t* tab_bounds, const int32_t* tab_kk, int ksize, const float* lut, uint8_t* tmp, uint8_t* crops,
-                        float* out, uint8_t* out_u8, void* stream);
+int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, int geometry, const int32_t* params_host, int32_t* params_dev,
+                        int n_views, const int32_t* tab_bounds, const int32_t* tab_kk, int ksize, const float* lut, uint8_t* tmp,
+                        uint8_t* crops, float* out, uint8_t* out_u8, void* stream);
 
 /* nn.Linear forward y = x w^T + b (optional ReLU): projector src/models/simclr.py:20-24, fc resnet.py:66. */
 int hipac_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,

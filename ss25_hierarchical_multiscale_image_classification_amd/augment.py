@@ -21,7 +21,8 @@ import torch
 from . import capi
 from .transforms import RandomResizedCrop
 
-PARAMS = 16  # int32 per view (include/hipac.h, hipac_augment_views)
+PARAMS = 24  # int32 per view (include/hipac.h, hipac_augment_views)
+IDENTITY_FIX = (65536, 0, 0, 0, 65536, 0)
 OUT = 224
 
 
@@ -47,7 +48,72 @@ def draw_simclr_view(index: int, width: int, height: int, scale=(0.08, 1.0), rat
         s = draw(max(0.0, 1.0 - jitter[2]), 1.0 + jitter[2])
         hue = int(draw(-jitter[3], jitter[3]) * 255) & 0xFF  # adjust_hue: np.uint8(int(hue_factor * 255))
     gray = 1 if float(torch.rand(1).item()) < p_gray else 0
-    return [index, top, left, h, w, flip, *ops, gray, _f32_bits(b), _f32_bits(c), _f32_bits(s), hue, 0]
+    return [index, top, left, h, w, flip, *ops, gray, _f32_bits(b), _f32_bits(c), _f32_bits(s), hue, 0, 0, *IDENTITY_FIX, 0]
+
+
+def pil_rotate_fixed(angle: float, w: int, h: int) -> Tuple[int, int, int, int, int, int]:
+    """The six 16.16 integers with which Pillow resamples ``img.rotate(angle, NEAREST, expand=False)``: Image.rotate's matrix
+    (cos / sin rounded to 15 decimals, rotation about (w/2, h/2)), then Geometry.c's affine_fixed (FIX(v) = FLOOR(v 65536 + .5),
+    half-pixel centre folded into a2 / a5); the transpose fast paths of 0 / 90 / 180 / 270 degrees as exact integer maps."""
+    angle = angle % 360.0
+    if angle == 0:
+        return IDENTITY_FIX
+    if angle == 180:
+        return (-65536, 0, (w - 1) << 16, 0, -65536, (h - 1) << 16)
+    if angle in (90, 270) and w == h:
+        return (0, -65536, (w - 1) << 16, 65536, 0, 0) if angle == 90 else (0, 65536, 0, -65536, 0, (h - 1) << 16)
+    rad = -math.radians(angle)
+    m = [round(math.cos(rad), 15), round(math.sin(rad), 15), 0.0, round(-math.sin(rad), 15), round(math.cos(rad), 15), 0.0]
+    cx, cy = w / 2, h / 2
+    m[2], m[5] = m[0] * -cx + m[1] * -cy + m[2], m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    floor_c = lambda x: int(math.floor(x)) if x < 0.0 else int(x)
+    fix = lambda v: floor_c(v * 65536.0 + 0.5)
+    return (fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5))
+
+
+def identity_view(index: int) -> List[int]:
+    """Geometry 1 with nothing drawn: the eval transform of a 224-pixel patch (normal patches, validation)."""
+    return [index, 0, 0, OUT, OUT, 0, -1, -1, -1, -1, 0, _f32_bits(1.0), _f32_bits(1.0), _f32_bits(1.0), 0, 0, 0, *IDENTITY_FIX, 0]
+
+
+def draw_train_view(index: int, jitter=(0.2, 0.2, 0.2, 0.1), degrees: float = 90.0) -> List[int]:
+    """The draws of ``transforms.train_transform()`` (src/main.py:417-425) in its order: RandomHorizontalFlip and
+    RandomVerticalFlip (``random``), RandomRotation's angle, ColorJitter's randperm(4) and four factors (torch)."""
+    hflip = 1 if random.random() < 0.5 else 0
+    vflip = 1 if random.random() < 0.5 else 0
+    angle = float(torch.empty(1).uniform_(-degrees, degrees).item())
+    ops = torch.randperm(4).tolist()
+    draw = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi).item())
+    b = draw(max(0.0, 1.0 - jitter[0]), 1.0 + jitter[0])
+    c = draw(max(0.0, 1.0 - jitter[1]), 1.0 + jitter[1])
+    s = draw(max(0.0, 1.0 - jitter[2]), 1.0 + jitter[2])
+    hue = int(draw(-jitter[3], jitter[3]) * 255) & 0xFF
+    return [index, 0, 0, OUT, OUT, hflip, *ops, 0, _f32_bits(b), _f32_bits(c), _f32_bits(s), hue, 0, vflip,
+            *pil_rotate_fixed(angle, OUT, OUT), 0]
+
+
+def draw_train_batch(indices: Sequence[int], augment_mask: Sequence[bool], rng: np.random.Generator, jitter=(0.2, 0.2, 0.2, 0.1),
+                     degrees: float = 90.0) -> np.ndarray:
+    """``draw_train_view``'s distributions for a batch (numpy generator); rows where ``augment_mask`` is False are the
+    identity (normal patches take the eval transform, src/main.py:440-444)."""
+    n = len(indices)
+    out = np.array([identity_view(int(i)) for i in indices], np.int32).reshape(n, PARAMS)
+    m = np.asarray(augment_mask, bool)
+    k = int(m.sum())
+    if k == 0:
+        return out
+    rows = np.where(m)[0]
+    out[rows, 5] = rng.random(k) < 0.5
+    out[rows, 16] = rng.random(k) < 0.5
+    out[rows, 6:10] = np.argsort(rng.random((k, 4)), axis=1)
+    for col, j in ((11, 0), (12, 1), (13, 2)):
+        out[rows, col] = rng.uniform(max(0.0, 1.0 - jitter[j]), 1.0 + jitter[j], k).astype(np.float32).view(np.int32)
+    out[rows, 14] = (rng.uniform(-jitter[3], jitter[3], k) * 255).astype(np.int64) & 0xFF
+    for r, a in zip(rows, rng.uniform(-degrees, degrees, k)):
+        out[r, 17:23] = pil_rotate_fixed(float(a), OUT, OUT)
+    return out
 
 
 def draw_simclr_batch(indices: Sequence[int], P: int, rng: np.random.Generator, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0),
@@ -81,6 +147,7 @@ def draw_simclr_batch(indices: Sequence[int], P: int, rng: np.random.Generator, 
     hue = (rng.uniform(-jitter[3], jitter[3], n) * 255).astype(np.int64) & 0xFF  # int() truncates toward zero, as astype does
     out[:, 14] = np.where(apply, hue, 0)
     out[:, 10] = rng.random(n) < p_gray
+    out[:, 17:23] = IDENTITY_FIX
     return out
 
 
@@ -115,7 +182,11 @@ class DevicePatchPool:
         """Decode every PNG of a ``PatchDataset(transform=None)`` once (host threads) and keep the pixels in HBM."""
         from PIL import Image
 
-        paths = list(base.image_paths)
+        if hasattr(base, "indices") and hasattr(base, "dataset"):  # torch.utils.data.Subset (the balanced validation set)
+            paths = [base.dataset.image_paths[i] for i in base.indices]
+            labels = [base.dataset.labels[i] for i in base.indices]
+        else:
+            paths, labels = list(base.image_paths), list(getattr(base, "labels", []))
 
         def load(p):
             with Image.open(p) as im:
@@ -133,7 +204,9 @@ class DevicePatchPool:
         step = max(1, (256 << 20) // (shp[0] * shp[1] * 3))
         for i in range(0, len(arrs), step):
             pool[i:i + step] = torch.from_numpy(np.stack(arrs[i:i + step])).to(dev)
-        return cls(pool, labels=list(getattr(base, "labels", [])) or None)
+        out = cls(pool, labels=labels or None)
+        out.paths = paths
+        return out
 
     def _buffers(self, n_views: int):
         key = n_views
@@ -144,12 +217,13 @@ class DevicePatchPool:
                                    torch.empty((n_views, OUT, OUT, 3), dtype=torch.uint8, device=dev))}
         return self._scratch[key]
 
-    def augment(self, params: np.ndarray, want_u8: bool = False, want_float: bool = True):
-        """params int32 [n_views, 16] (host) -> float32 [n_views, 3, 224, 224] on the device (and / or the uint8
-        [n_views, 224, 224, 3] image before ToTensor)."""
+    def augment(self, params: np.ndarray, want_u8: bool = False, want_float: bool = True, geometry: int = 0):
+        """params int32 [n_views, 24] (host) -> float32 [n_views, 3, 224, 224] on the device (and / or the uint8
+        [n_views, 224, 224, 3] image before ToTensor).  ``geometry``: 0 = resized crop (SimCLR), 1 = flips + rotation
+        (the classifier loops' transform; 224-pixel patches)."""
         params = np.ascontiguousarray(params, dtype=np.int32)
         if params.ndim != 2 or params.shape[1] != PARAMS:
-            raise capi.HipacError("augment: params must be int32 [n_views, 16]")
+            raise capi.HipacError("augment: params must be int32 [n_views, 24]")
         n = params.shape[0]
         pdev, tmp, crops = self._buffers(n)
         # the parameters travel through a ring of PINNED host buffers: an asynchronous copy from pageable memory would make the
@@ -168,7 +242,7 @@ class DevicePatchPool:
         out_u8 = torch.empty((n, OUT, OUT, 3), dtype=torch.uint8, device=self.device) if want_u8 else None
         lib = capi.load_library()
         with torch.cuda.device(self.device):
-            capi._check(lib.hipac_augment_views(self.patches.data_ptr(), self.n, self.P, host.data_ptr(), pdev.data_ptr(), n,
+            capi._check(lib.hipac_augment_views(self.patches.data_ptr(), self.n, self.P, int(geometry), host.data_ptr(), pdev.data_ptr(), n,
                                                 self.tab_bounds.data_ptr(), self.tab_kk.data_ptr(), self.ksize, self.lut.data_ptr(),
                                                 tmp.data_ptr(), crops.data_ptr(), out.data_ptr() if out is not None else None,
                                                 out_u8.data_ptr() if out_u8 is not None else None, capi._stream()),
@@ -226,6 +300,53 @@ class DeviceSimCLRLoader:
                 rows[0], rows[1] = draw_simclr_batch(b, P, self._rng), draw_simclr_batch(b, P, self._rng)
             x = self.pool.augment(rows.reshape(-1, PARAMS))
             yield x[:len(b)], x[len(b):]
+        self.epoch += 1
+
+
+class DeviceClassifierLoader:
+    """Batches of (images float32 [B, 3, 224, 224] on the device, labels int64 [B] on the host, indices) from a pool of
+    224-pixel patches: what the classifier loops' DataLoader yields (src/main.py:440-452) -- tumour patches through
+    ``train_transform``, normal patches through the eval transform; ``augment=False``: every patch through the eval
+    transform (validation)."""
+
+    def __init__(self, pool: DevicePatchPool, batch_size: int, shuffle: bool = True, augment: bool = True, seed: int = 0, rank: int = 0,
+                 world: int = 1, indices: Optional[Sequence[int]] = None):
+        if pool.P != OUT:
+            raise capi.HipacError("DeviceClassifierLoader: the flips / rotation / jitter act on 224-pixel patches (level 3); "
+                                  "other levels keep the host transforms")
+        if pool.labels is None:
+            raise capi.HipacError("DeviceClassifierLoader: the pool has no labels")
+        self.pool, self.batch_size, self.shuffle, self.augment = pool, int(batch_size), shuffle, augment
+        self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
+        self.indices = list(range(len(pool))) if indices is None else [int(i) for i in indices]
+        self._rng = np.random.default_rng([seed, rank, 7])
+
+    def __len__(self):
+        return math.ceil(len(self.indices) / self.batch_size)
+
+    def __iter__(self):
+        n = len(self.indices)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = [self.indices[i] for i in torch.randperm(n, generator=g).tolist()]
+        else:
+            order = list(self.indices)
+        for i in range(0, n, self.batch_size):
+            b = order[i:i + self.batch_size]
+            if self.world > 1:
+                if self.shuffle:  # training: equal contiguous shares of the global batch (dist.RankBatchSampler)
+                    per = len(b) // self.world
+                    b = b[self.rank * per:(self.rank + 1) * per]
+                else:  # validation: every sample once
+                    from .dist import shard_columns
+
+                    i0, i1 = shard_columns(len(b), self.rank, self.world)
+                    b = b[i0:i1]
+            if not b:
+                continue
+            labels = [self.pool.labels[j] for j in b]
+            rows = draw_train_batch(b, [self.augment and lab == 1 for lab in labels], self._rng)
+            yield self.pool.augment(rows, geometry=1), torch.tensor(labels, dtype=torch.int64), b
         self.epoch += 1
 
 

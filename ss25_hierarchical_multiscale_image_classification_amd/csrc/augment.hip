@@ -1,6 +1,8 @@
-// SimCLR view augmentation on the device (SURVEY a-12: src/models/simclr.py:57-66, get_simclr_transform):
+// Training-view augmentation on the device.  SimCLR (SURVEY a-12: src/models/simclr.py:57-66, get_simclr_transform):
 //     RandomResizedCrop(224) -> RandomHorizontalFlip -> RandomApply([ColorJitter(.4, .4, .4, .1)], p = .8)
 //     -> RandomGrayscale(p = .2) -> ToTensor -> Normalize
+// and the classifier loops' transform of tumour patches (a-13: src/main.py:417-425; 224-pixel patches): flips, RandomRotation(90),
+// ColorJitter(.2, .2, .2, .1), Resize (the identity there), ToTensor, Normalize --
 // on patches that stay resident in HBM as uint8 [N][P][P][3] (a pool of decoded PNGs: 150 KB per 224-pixel patch, i.e.
 // 1.9 M patches in 288 GB).  The reference runs these transforms per sample on DataLoader workers through Pillow
 // (torchvision's PIL backend); at the native step's rate (14 k view pairs/s in fp16) that host path is 10x too slow, so the
@@ -25,7 +27,7 @@
 
 namespace hipac {
 
-constexpr int kAugParams = 16;  // int32 per view, see include/hipac.h
+constexpr int kAugParams = 24;  // int32 per view, see include/hipac.h
 constexpr int kOut = 224;
 
 __device__ __forceinline__ int clip8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -75,6 +77,28 @@ __global__ __launch_bounds__(256) void aug_vpass_kernel(const unsigned char* __r
   }
   unsigned char* o = out + (((size_t)v * kOut + oy) * kOut + (flip ? kOut - 1 - ox : ox)) * 3;
   o[0] = (unsigned char)clip8i(a0 >> 22), o[1] = (unsigned char)clip8i(a1 >> 22), o[2] = (unsigned char)clip8i(a2 >> 22);
+}
+
+// geometry 1 (the classifier loops' train_transform on 224-pixel patches, src/main.py:417-425): RandomHorizontalFlip,
+// RandomVerticalFlip, then RandomRotation's Image.rotate(angle, NEAREST, fillcolor = 0) = libImaging/Geometry.c affine_fixed:
+// 16.16 fixed-point source coordinates xx = a2 + x a0 + y a1, yy = a5 + x a3 + y a4 (the six integers are computed on the host
+// exactly as Image.rotate / affine_fixed compute them), pixel (yy >> 16, xx >> 16) of the flipped image or black outside
+__global__ __launch_bounds__(256) void aug_affine_kernel(const unsigned char* __restrict__ pool, const int* __restrict__ params,
+                                                         unsigned char* __restrict__ out) {
+  const int v = blockIdx.y;
+  const int* pr = params + v * kAugParams;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= kOut * kOut) return;
+  const int y = t / kOut, x = t - y * kOut;
+  const int xin = (pr[19] + x * pr[17] + y * pr[18]) >> 16, yin = (pr[22] + x * pr[20] + y * pr[21]) >> 16;
+  unsigned char* o = out + ((size_t)v * kOut * kOut + t) * 3;
+  if (xin >= 0 && xin < kOut && yin >= 0 && yin < kOut) {
+    const int xs = pr[5] ? kOut - 1 - xin : xin, ys = pr[16] ? kOut - 1 - yin : yin;
+    const unsigned char* src = pool + (((size_t)pr[0] * kOut + ys) * kOut + xs) * 3;
+    o[0] = src[0], o[1] = src[1], o[2] = src[2];
+  } else {
+    o[0] = o[1] = o[2] = 0;
+  }
 }
 
 // ImagingBlend(in1, in2, alpha) for one byte (libImaging/Blend.c): float arithmetic, one multiply, one add
@@ -214,30 +238,43 @@ using namespace hipac;
 
 extern "C" {
 
-int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, const int32_t* params_host, int32_t* params_dev, int n_views,
-                        const int32_t* tab_bounds, const int32_t* tab_kk, int ksize, const float* lut, uint8_t* tmp, uint8_t* crops,
-                        float* out, uint8_t* out_u8, void* stream) {
-  HIPAC_REQUIRE(pool && params_host && params_dev && tab_bounds && tab_kk && lut && tmp && crops && (out || out_u8), HIPAC_EINVAL,
-                "augment_views: null argument");
-  HIPAC_REQUIRE(n_pool > 0 && P >= 1 && P <= 4096 && n_views > 0 && n_views <= 65535 && ksize >= 1, HIPAC_EINVAL,
-                "augment_views: bad size (P %d, views %d, ksize %d)", P, n_views, ksize);
+int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, int geometry, const int32_t* params_host, int32_t* params_dev,
+                        int n_views, const int32_t* tab_bounds, const int32_t* tab_kk, int ksize, const float* lut, uint8_t* tmp,
+                        uint8_t* crops, float* out, uint8_t* out_u8, void* stream) {
+  HIPAC_REQUIRE(pool && params_host && params_dev && lut && crops && (out || out_u8), HIPAC_EINVAL, "augment_views: null argument");
+  HIPAC_REQUIRE(geometry == 0 || geometry == 1, HIPAC_EINVAL, "augment_views: geometry %d (0: resized crop, 1: flips + rotation)", geometry);
+  HIPAC_REQUIRE(geometry == 1 || (tab_bounds && tab_kk && tmp && ksize >= 1), HIPAC_EINVAL, "augment_views: the resized crop needs its tables");
+  HIPAC_REQUIRE(geometry == 0 || P == kOut, HIPAC_EINVAL, "augment_views: flips + rotation act on 224-pixel patches (P = %d)", P);
+  HIPAC_REQUIRE(n_pool > 0 && P >= 1 && P <= 4096 && n_views > 0 && n_views <= 65535, HIPAC_EINVAL,
+                "augment_views: bad size (P %d, views %d)", P, n_views);
   // the kernels index the pool with these numbers: check them where they are still host memory
   for (int v = 0; v < n_views; ++v) {
     const int32_t* pr = params_host + (size_t)v * kAugParams;
-    const bool crop_ok = pr[0] >= 0 && pr[0] < n_pool && pr[3] >= 1 && pr[4] >= 1 && pr[1] >= 0 && pr[2] >= 0 &&
-                         (int64_t)pr[1] + pr[3] <= P && (int64_t)pr[2] + pr[4] <= P;
+    const bool crop_ok = pr[0] >= 0 && pr[0] < n_pool &&
+                         (geometry == 1 || (pr[3] >= 1 && pr[4] >= 1 && pr[1] >= 0 && pr[2] >= 0 && (int64_t)pr[1] + pr[3] <= P &&
+                                            (int64_t)pr[2] + pr[4] <= P));
     bool ops_ok = true;
     for (int o = 0; o < 4; ++o) ops_ok = ops_ok && pr[6 + o] >= -1 && pr[6 + o] <= 3;
-    HIPAC_REQUIRE(crop_ok && ops_ok, HIPAC_EINVAL, "augment_views: view %d: source %d, crop (%d, %d, %d, %d) of a %d-pixel patch, ops %d %d %d %d",
-                  v, pr[0], pr[1], pr[2], pr[3], pr[4], P, pr[6], pr[7], pr[8], pr[9]);
+    // 16.16 coordinates of a 224-pixel image must stay inside int32 (Pillow's check_fixed allows +-32768 pixels; a rotation
+    // about the centre stays within a few hundred)
+    bool fix_ok = true;
+    if (geometry == 1)
+      for (int k = 17; k <= 22; ++k) fix_ok = fix_ok && pr[k] > -(1 << 26) && pr[k] < (1 << 26);
+    HIPAC_REQUIRE(crop_ok && ops_ok && fix_ok, HIPAC_EINVAL,
+                  "augment_views: view %d: source %d, crop (%d, %d, %d, %d) of a %d-pixel patch, ops %d %d %d %d", v, pr[0], pr[1],
+                  pr[2], pr[3], pr[4], P, pr[6], pr[7], pr[8], pr[9]);
   }
   hipStream_t s = (hipStream_t)stream;
   HIPAC_CHECK_HIP(hipMemcpyAsync(params_dev, params_host, (size_t)n_views * kAugParams * sizeof(int32_t), hipMemcpyHostToDevice, s));
   const int32_t* params = params_dev;
-  dim3 gh((unsigned)(((size_t)P * kOut + 255) / 256), (unsigned)n_views);
-  hipLaunchKernelGGL(aug_hpass_kernel, gh, dim3(256), 0, s, pool, P, params, tab_bounds, tab_kk, ksize, tmp);
   dim3 gv((kOut * kOut + 255) / 256, (unsigned)n_views);
-  hipLaunchKernelGGL(aug_vpass_kernel, gv, dim3(256), 0, s, (const unsigned char*)tmp, P, params, tab_bounds, tab_kk, ksize, crops);
+  if (geometry == 0) {
+    dim3 gh((unsigned)(((size_t)P * kOut + 255) / 256), (unsigned)n_views);
+    hipLaunchKernelGGL(aug_hpass_kernel, gh, dim3(256), 0, s, pool, P, params, tab_bounds, tab_kk, ksize, tmp);
+    hipLaunchKernelGGL(aug_vpass_kernel, gv, dim3(256), 0, s, (const unsigned char*)tmp, P, params, tab_bounds, tab_kk, ksize, crops);
+  } else {
+    hipLaunchKernelGGL(aug_affine_kernel, gv, dim3(256), 0, s, pool, params, crops);
+  }
   constexpr int LDS = kOut * kOut * 3 + 64;
   static bool attr_done[64] = {};
   {

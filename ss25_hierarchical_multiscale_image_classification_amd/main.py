@@ -77,8 +77,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="arithmetic of the classifier training step: fp16 = the reference's autocast + GradScaler "
                         "(src/main.py:499-508), fp32 = exact f32 MFMA")
     p.add_argument("--device_aug", action="store_true",
-                   help="SimCLR pre-training: keep the decoded patches in HBM and make both views of a step on the device "
-                        "(hipac_augment_views) instead of in DataLoader workers")
+                   help="training loops: keep the decoded patches in HBM and make every batch's augmented views on the device "
+                        "(hipac_augment_views; classifier loops: 224-pixel patches) instead of in DataLoader workers")
     p.add_argument("--simclr_precision", choices=["fp16", "fp32"], default="fp32",
                    help="arithmetic of the SimCLR pre-training step (the reference's loop is fp32, src/models/simclr.py:85-96)")
     p.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)

@@ -89,7 +89,9 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     ``autocast()`` + ``GradScaler`` arithmetic (:499-508, :578-587: fp16 operands, fp32 accumulation and master weights,
     dynamic loss scale), "fp32" = the exact f32 MFMA; validation scores with the HIP inference path in ``precision``.  ``self_supervised``: pre-trains SimCLR when
     ``simclr_path`` does not exist (:556-557), then starts the classifier from that encoder -- what the reference
-    means to do (its constructor call raises a TypeError there)."""
+    means to do (its constructor call raises a TypeError there).  ``device_aug`` (additive): both sets'
+    decoded patches stay in HBM and every batch is transformed on the device (``augment.DeviceClassifierLoader``; SimCLR
+    pre-training: ``augment.DeviceSimCLRLoader``) instead of in DataLoader workers."""
     from .dist import all_reduce_sum_scalars, rank_world
     from .train_native import NativeClassifierTrainer
     from .weights import canonical_state_dict
@@ -118,6 +120,15 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
             if not k.startswith("projector.") and ("model." + k) in sd:
                 sd["model." + k] = v
         model.load_state_dict(sd)
+    if device_aug:
+        # the decoded patches of both sets stay in HBM; flips / rotation / jitter of the tumour patches and the eval transform
+        # of the others are made per batch on the device (augment.py); 224-pixel patches only (the level `--train` reads)
+        from .augment import DeviceClassifierLoader, DevicePatchPool
+
+        train_loader = DeviceClassifierLoader(DevicePatchPool.from_patch_dataset(train_ds, device=device), batch_size, shuffle=True,
+                                              augment=True, seed=0, rank=rank, world=world)
+        val_loader = DeviceClassifierLoader(DevicePatchPool.from_patch_dataset(val_ds, device=device), batch_size, shuffle=False,
+                                            augment=False, rank=rank, world=world)
     w = class_weights(train_ds, strategy)
     trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w, precision=train_precision)
     trainer.sync_from_rank0()

@@ -29,7 +29,8 @@ def _images(n, P, seed):
 
 def _view(idx, P, ops=(-1, -1, -1, -1), b=1.0, c=1.0, s=1.0, hue=0, gray=0, crop=None, flip=0):
     top, left, h, w = crop if crop is not None else (0, 0, P, P)
-    return [idx, top, left, h, w, flip, *ops, gray, augment._f32_bits(b), augment._f32_bits(c), augment._f32_bits(s), hue & 255, 0]
+    return [idx, top, left, h, w, flip, *ops, gray, augment._f32_bits(b), augment._f32_bits(c), augment._f32_bits(s), hue & 255, 0,
+            0, *augment.IDENTITY_FIX, 0]
 
 
 def test_colour_operations_equal_pillow():
@@ -154,3 +155,76 @@ def test_device_loader_feeds_the_native_simclr_step(tmp_path):
     model, hist = S.pretrain_simclr(str(tmp_path / "level_3"), epochs=1, batch_size=4, out_dir=str(tmp_path), max_steps=2, verbose=False,
                                     device_aug=True, precision="fp16")
     assert len(hist) == 1 and np.isfinite(hist[0]) and (tmp_path / "simclr_encoder.pth").exists()
+
+
+def test_flips_and_rotation_equal_pillow():
+    """Geometry 1: RandomHorizontalFlip / RandomVerticalFlip / Image.rotate(angle, NEAREST, fillcolor=0) -- Pillow's affine_fixed
+    path with the matrix Image.rotate builds, the transpose fast paths of 0 / 90 / 180 / 270 degrees included."""
+    imgs = _images(3, 224, 9)
+    pool = augment.DevicePatchPool(imgs.cuda())
+    rng = np.random.default_rng(2)
+    angles = list(rng.uniform(-90, 90, 40)) + [0.0, 90.0, -90.0, 180.0, 270.0, 360.0, 45.0, -45.0, 1e-9, -1e-9, 89.999999, 0.5, -0.5]
+    rows, refs = [], []
+    for k, a in enumerate(angles):
+        i, hf, vf = k % 3, (k >> 1) & 1, (k >> 2) & 1
+        pil = Image.fromarray(imgs[i].numpy(), "RGB")
+        pil = pil.transpose(Image.FLIP_LEFT_RIGHT) if hf else pil
+        pil = pil.transpose(Image.FLIP_TOP_BOTTOM) if vf else pil
+        refs.append(np.array(pil.rotate(float(a), resample=Image.NEAREST, expand=False, fillcolor=0)))
+        row = augment.identity_view(i)
+        row[5], row[16] = hf, vf
+        row[17:23] = augment.pil_rotate_fixed(float(a), 224, 224)
+        rows.append(row)
+    _, got = pool.augment(np.array(rows, np.int32), want_u8=True, geometry=1)
+    got = got.cpu().numpy()
+    for k, ref in enumerate(refs):
+        assert np.array_equal(got[k], ref), (angles[k], int((got[k] != ref).any(-1).sum()))
+
+
+def test_train_transform_equals_host_transforms_under_the_same_draws():
+    """`transforms.train_transform()` (src/main.py:417-425 on Pillow, host) against geometry 1 with `draw_train_view`, same seeds;
+    and the eval transform of a 224-pixel patch = the identity row."""
+    imgs = _images(10, 224, 31)
+    pool = augment.DevicePatchPool(imgs.cuda())
+    T, E = transforms.train_transform(), transforms.eval_transform()
+    torch.manual_seed(77), random.seed(77)
+    host = [T(Image.fromarray(imgs[i].numpy(), "RGB")) for i in range(imgs.shape[0])]
+    torch.manual_seed(77), random.seed(77)
+    rows = [augment.draw_train_view(i) for i in range(imgs.shape[0])]
+    got = pool.augment(np.array(rows, np.int32), geometry=1).cpu()
+    for k, ref in enumerate(host):
+        assert torch.equal(got[k], ref), (k, rows[k], float((got[k] - ref).abs().max()))
+    got = pool.augment(np.array([augment.identity_view(i) for i in range(3)], np.int32), geometry=1).cpu()
+    for i in range(3):
+        assert torch.equal(got[i], E(Image.fromarray(imgs[i].numpy(), "RGB")))
+    with pytest.raises(capi.HipacError):  # flips + rotation act at 224 pixels only
+        augment.DevicePatchPool(_images(2, 448, 1).cuda()).augment(np.array([augment.identity_view(0)], np.int32), geometry=1)
+
+
+def test_classifier_loop_on_device_loaders(tmp_path):
+    """`train_resnet_classifier(device_aug=True)`: both sets' patches in HBM, batches made on the device, the native step."""
+    from ss25_hierarchical_multiscale_image_classification_amd import train
+    from ss25_hierarchical_multiscale_image_classification_amd.patch_dataset import PatchDataset
+
+    imgs = _images(24, 224, 41)
+    root = tmp_path / "level_3"
+    for s in range(3):
+        d = root / f"tumor_00{s}"
+        d.mkdir(parents=True)
+        for i in range(8):
+            k = 8 * s + i
+            Image.fromarray(imgs[k].numpy(), "RGB").save(d / f"tumor_00{s}_x{i * 224}_y0_{'tumor' if i % 2 else 'normal'}.png")
+    ds = PatchDataset(str(root), transform=None)
+    pool = augment.DevicePatchPool.from_patch_dataset(ds)
+    ld = augment.DeviceClassifierLoader(pool, 6, shuffle=True, augment=True, seed=3)
+    seen = []
+    for x, labels, idx in ld:
+        assert x.is_cuda and x.shape[1:] == (3, 224, 224) and labels.tolist() == [pool.labels[j] for j in idx]
+        seen += idx
+        for j, lab, xi in zip(idx, labels.tolist(), x):
+            if lab == 0:  # normal patches: the eval transform, i.e. the normalised pixels themselves
+                assert torch.equal(xi.cpu(), transforms.eval_transform()(Image.open(pool.paths[j]).convert("RGB")))
+    assert sorted(seen) == list(range(24))
+    model, hist = train.train_resnet_classifier(str(root), strategy="weighted_loss", epochs=1, batch_size=8, max_steps=2,
+                                                save_path=str(tmp_path / "clf.pth"), device_aug=True)
+    assert len(hist) == 1 and np.isfinite(hist[0][0]) and 0.0 <= hist[0][2] <= 1.0 and (tmp_path / "clf.pth").exists()
