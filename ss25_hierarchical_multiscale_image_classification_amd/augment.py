@@ -208,6 +208,32 @@ class DevicePatchPool:
         out.paths = paths
         return out
 
+    @classmethod
+    def from_slides(cls, slides, level: int = 3, stride: Optional[int] = None) -> "DevicePatchPool":
+        """The kept windows of ``level`` of every slide, straight from the pyramids in HBM: what ``--patch`` would write as
+        PNGs (src/main.py:722-726) and ``PatchDataset`` read back -- PNG is lossless, so at level 3 (224-pixel windows) the
+        pool holds exactly those pixels, without the disk round trip; at other levels it holds the windows ALREADY resized
+        to 224 (the PNG tree keeps them at P x P).  ``labels``: 1 tumour / 0 normal from the slide's mask; ``meta``: int32
+        [N, 4] (level, x, y, label); ``slide_names``: per patch."""
+        from . import extract
+
+        parts, labels, names, metas = [], [], [], []
+        for sl in slides:
+            lw = extract.LevelWindows(sl, level, stride)
+            k = lw.kept_index()
+            if k.numel() == 0:
+                continue
+            parts.append(lw.patches(k))
+            m = lw.meta(k)
+            metas.append(m.cpu())
+            labels += m[:, 3].cpu().tolist()
+            names += [sl.name] * int(k.numel())
+        if not parts:
+            raise capi.HipacError("DevicePatchPool.from_slides: no window passed the whiteness filter")
+        out = cls(torch.cat(parts), labels=labels)
+        out.slide_names, out.meta = names, torch.cat(metas)
+        return out
+
     def _buffers(self, n_views: int):
         key = n_views
         if key not in self._scratch:

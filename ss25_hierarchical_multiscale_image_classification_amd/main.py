@@ -79,6 +79,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device_aug", action="store_true",
                    help="training loops: keep the decoded patches in HBM and make every batch's augmented views on the device "
                         "(hipac_augment_views; classifier loops: 224-pixel patches) instead of in DataLoader workers")
+    p.add_argument("--from_slides", action="store_true",
+                   help="--train / --train_strategy: no PNG tree -- the kept windows go from the slides in HBM straight into the "
+                        "training pool (implies the device input pipeline)")
     p.add_argument("--simclr_precision", choices=["fp16", "fp32"], default="fp32",
                    help="arithmetic of the SimCLR pre-training step (the reference's loop is fp32, src/models/simclr.py:85-96)")
     p.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
@@ -226,6 +229,12 @@ def cmd_train(args, strategy: Optional[str]):
 
     level = int(args.patch_level) if args.patch_level != "all" else 3
     patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
+    if args.from_slides:
+        slides = [make() for _, make in list_slides(args)]  # every rank holds every slide: batches are shared out, not slides
+        train_resnet_classifier(None, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size, precision=args.precision,
+                                simclr_epochs=args.simclr_epochs, max_steps=args.max_steps, train_precision=args.train_precision,
+                                simclr_precision=args.simclr_precision, slides=slides, level=level)
+        return 0
     if not (os.path.isdir(patch_dir) and os.listdir(patch_dir)):
         print("[ERROR] Patches must be extracted before training.")
         return 1

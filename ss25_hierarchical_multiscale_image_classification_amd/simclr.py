@@ -91,7 +91,7 @@ def get_simclr_transform():
 
 def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr: float = 1e-3, device: str = "cuda",
                     num_workers: int = 8, out_dir: str = ".", max_steps: Optional[int] = None, verbose: bool = True,
-                    final_path: Optional[str] = None, precision: str = "fp32", device_aug: bool = False):
+                    final_path: Optional[str] = None, precision: str = "fp32", device_aug: bool = False, pool=None):
     """src/models/simclr.py:68-124 with the step on the native kernels: PatchDataset(transform=None) ->
     SimCLRDataset(two augmented views) -> DataLoader(batch_size, shuffle) -> per batch
     ``z_i = model(x_i); z_j = model(x_j); loss = nt_xent_loss(z_i, z_j); backward; Adam(lr).step()``.
@@ -114,9 +114,17 @@ def pretrain_simclr(patch_dir: str, epochs: int = 200, batch_size: int = 512, lr
     from .train_native import NativeSimCLRTrainer
 
     rank, world = rank_world()
-    base = PatchDataset(patch_dir, transform=None)
-    ds = SimCLRDataset(base, transform=get_simclr_transform())
-    if device_aug:
+    if pool is not None:  # (additive) an ``augment.DevicePatchPool`` made elsewhere, e.g. straight from the slides: no PNG tree
+        from .augment import DeviceSimCLRLoader
+
+        loader = DeviceSimCLRLoader(pool, batch_size, shuffle=True, seed=0, rank=rank, world=world)
+        base = ds = None
+    else:
+        base = PatchDataset(patch_dir, transform=None)
+        ds = SimCLRDataset(base, transform=get_simclr_transform())
+    if pool is not None:
+        pass
+    elif device_aug:
         from .augment import DevicePatchPool, DeviceSimCLRLoader
 
         loader = DeviceSimCLRLoader(DevicePatchPool.from_patch_dataset(base, device=device, workers=max(1, num_workers)), batch_size,

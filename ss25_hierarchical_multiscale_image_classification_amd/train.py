@@ -6,6 +6,7 @@ validation scoring uses the HIP inference path.  Data loading and augmentation s
 from __future__ import annotations
 
 import os
+import random
 from typing import Optional
 
 import numpy as np
@@ -55,6 +56,62 @@ def get_dataloaders(patch_dir: str, test_ratio: float = 0.2, batch_size: int = 5
             DataLoader(val_ds, batch_size=batch_size, shuffle=False), train_ds, val_ds)
 
 
+class _PoolView:
+    """The slice of a DevicePatchPool a loop trains / validates on, with the two things the loops ask a dataset."""
+
+    def __init__(self, pool, indices):
+        self.pool, self.indices = pool, list(indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+    def get_class_counts(self):
+        from collections import Counter
+
+        return dict(Counter(self.pool.labels[i] for i in self.indices))
+
+
+def get_device_loaders(slides, level: int = 3, test_ratio: float = 0.2, batch_size: int = 512, balanced: bool = False,
+                       rank: int = 0, world: int = 1, stride: Optional[int] = None):
+    """``get_dataloaders`` without the PNG tree: the kept windows of ``level`` go from the slides in HBM straight into one
+    ``DevicePatchPool`` (``--patch``'s PNGs are lossless: the same pixels and labels), the split is the same slide-level
+    split (sorted slide names, random_state=42), ``balanced`` draws the same number of patches per class
+    (src/main.py:432-438), the validation set is balanced with default_rng(42) (:446-450)."""
+    from sklearn.model_selection import train_test_split
+
+    from .augment import DeviceClassifierLoader, DevicePatchPool
+
+    pool = DevicePatchPool.from_slides(slides, level=level, stride=stride)
+    names = sorted(set(pool.slide_names))
+    if len(names) > 1:
+        train_slides, val_slides = train_test_split(names, test_size=test_ratio, random_state=42)
+    else:
+        train_slides = val_slides = names
+    tr_set, va_set = set(train_slides), set(val_slides)
+    by_class = {0: [], 1: []}
+    for i, (n, lab) in enumerate(zip(pool.slide_names, pool.labels)):
+        if n in tr_set:
+            by_class[lab].append(i)
+    train_idx = []
+    if balanced:
+        floor = min(len(v) for v in by_class.values())
+        for lab, idx in by_class.items():
+            train_idx += random.sample(idx, min(floor, SAMPLES_PER_CLASS, len(idx)))
+    else:
+        train_idx = by_class[0] + by_class[1]
+    val_idx = np.array([i for i, n in enumerate(pool.slide_names) if n in va_set], np.int64)
+    labels = np.array([pool.labels[i] for i in val_idx])
+    tum, nor = np.where(labels == 1)[0], np.where(labels == 0)[0]
+    if len(tum) and len(nor):
+        n_min = min(len(tum), len(nor))
+        rng = np.random.default_rng(42)
+        val_idx = val_idx[np.concatenate([rng.choice(tum, n_min, replace=False), rng.choice(nor, n_min, replace=False)])]
+    train_ds, val_ds = _PoolView(pool, train_idx), _PoolView(pool, val_idx.tolist())
+    return (DeviceClassifierLoader(pool, batch_size, shuffle=True, augment=True, seed=0, rank=rank, world=world, indices=train_idx),
+            DeviceClassifierLoader(pool, batch_size, shuffle=False, augment=False, rank=rank, world=world, indices=val_idx.tolist()),
+            train_ds, val_ds, pool)
+
+
 def _val_share(n: int, batch_size: int, rank: int, world: int):
     """Validation indices of this rank (a contiguous range: every sample is scored exactly once), in batches."""
     from .dist import shard_columns
@@ -82,7 +139,8 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
                             batch_size: int = 512, precision: str = "bf16", lr: float = 1e-4,
                             save_path: Optional[str] = None, device: str = "cuda", simclr_epochs: int = 200,
                             simclr_path: str = "simclr_encoder.pth", max_steps: Optional[int] = None,
-                            train_precision: str = "fp16", simclr_precision: str = "fp32", device_aug: bool = False):
+                            train_precision: str = "fp16", simclr_precision: str = "fp32", device_aug: bool = False,
+                            slides=None, level: int = 3):
     """``train_resnet_classifier`` (strategy None, 30 epochs, src/main.py:472-534) and
     ``train_resnet_classifier_strategic`` (5 epochs, :536-606).  The training step runs on the native kernels
     (``train_native.NativeClassifierTrainer``) in ``train_precision``: "fp16" (default) = the reference's
@@ -91,15 +149,23 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     ``simclr_path`` does not exist (:556-557), then starts the classifier from that encoder -- what the reference
     means to do (its constructor call raises a TypeError there).  ``device_aug`` (additive): both sets'
     decoded patches stay in HBM and every batch is transformed on the device (``augment.DeviceClassifierLoader``; SimCLR
-    pre-training: ``augment.DeviceSimCLRLoader``) instead of in DataLoader workers."""
+    pre-training: ``augment.DeviceSimCLRLoader``) instead of in DataLoader workers.  ``slides`` (additive; a list of
+    ``extract.DeviceSlide``): no PNG tree at all -- the kept windows of ``level`` go from the pyramids in HBM into the pool
+    (``get_device_loaders``), ``patch_dir`` is not read."""
     from .dist import all_reduce_sum_scalars, rank_world
     from .train_native import NativeClassifierTrainer
     from .weights import canonical_state_dict
 
     rank, world = rank_world()  # > 1 under ``main.py --world_size N``: one process per GPU, global batch = batch_size
     epochs = epochs if epochs is not None else (30 if strategy is None else 5)  # :494 / :575
-    train_loader, val_loader, train_ds, val_ds = get_dataloaders(patch_dir, 0.2, batch_size,
-                                                                 balanced=strategy == "balanced", rank=rank, world=world)
+    pool_all = None
+    if slides is not None:
+        train_loader, val_loader, train_ds, val_ds, pool_all = get_device_loaders(slides, level, 0.2, batch_size,
+                                                                                   balanced=strategy == "balanced", rank=rank, world=world)
+        device_aug = False  # the loaders are device loaders already
+    else:
+        train_loader, val_loader, train_ds, val_ds = get_dataloaders(patch_dir, 0.2, batch_size,
+                                                                     balanced=strategy == "balanced", rank=rank, world=world)
     dev = torch.device(device)
     model = ResNet18Classifier().set_precision(precision)
     if strategy == "self_supervised":
@@ -109,7 +175,7 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
             # the final checkpoint goes to simclr_path itself, whatever its basename
             pretrain_simclr(patch_dir, epochs=simclr_epochs, batch_size=batch_size, device=device,
                             out_dir=os.path.dirname(simclr_path) or ".", max_steps=max_steps, final_path=simclr_path,
-                            precision=simclr_precision, device_aug=device_aug)
+                            precision=simclr_precision, device_aug=device_aug, pool=pool_all)
             if world > 1:
                 torch.distributed.barrier()  # rank 0 wrote the file
         if not os.path.exists(simclr_path):

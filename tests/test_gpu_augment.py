@@ -228,3 +228,52 @@ def test_classifier_loop_on_device_loaders(tmp_path):
     model, hist = train.train_resnet_classifier(str(root), strategy="weighted_loss", epochs=1, batch_size=8, max_steps=2,
                                                 save_path=str(tmp_path / "clf.pth"), device_aug=True)
     assert len(hist) == 1 and np.isfinite(hist[0][0]) and 0.0 <= hist[0][2] <= 1.0 and (tmp_path / "clf.pth").exists()
+
+
+def test_pool_from_slides_equals_the_png_tree(tmp_path):
+    """Level 3: the pool made straight from the slides in HBM holds the pixels `--patch` writes as PNGs and `PatchDataset`
+    reads back, with the same labels (src/main.py:705-726)."""
+    from ss25_hierarchical_multiscale_image_classification_amd import extract
+    from ss25_hierarchical_multiscale_image_classification_amd.patch_dataset import PatchDataset
+
+    slides = [extract.DeviceSlide.synthetic(9000, 7000, seed=61 + i, name=f"tumor_06{i}", with_polygons=True) for i in range(2)]
+    pool = augment.DevicePatchPool.from_slides(slides, level=3)
+    root = tmp_path / "level_3"
+    for sl in slides:
+        extract.save_patch_pngs(sl, 3, str(root))
+    ds = PatchDataset(str(root), transform=None)
+    assert len(ds) == len(pool) > 20 and pool.P == 224
+    by_key = {(n, int(m[1]), int(m[2])): i for i, (n, m) in enumerate(zip(pool.slide_names, pool.meta))}
+    import re
+    for path, lab in zip(ds.image_paths, ds.labels):
+        mm = re.search(r"(tumor_\d+)_x(\d+)_y(\d+)_", path)
+        i = by_key[(mm.group(1), int(mm.group(2)), int(mm.group(3)))]
+        assert pool.labels[i] == lab
+        assert np.array_equal(pool.patches[i].cpu().numpy(), np.array(Image.open(path).convert("RGB")))
+    ld = augment.DeviceClassifierLoader(pool, 16, seed=2)
+    x, labels, idx = next(iter(ld))
+    assert x.shape == (16, 3, 224, 224) and labels.tolist() == [pool.labels[j] for j in idx]
+
+
+def test_training_loops_straight_from_slides(tmp_path):
+    """No PNG tree: `train_resnet_classifier(slides=...)` builds its pools from the pyramids in HBM (slide-level split as the
+    reference's), runs the native steps on device-made batches, validates, saves; `self_supervised` pre-trains SimCLR on the
+    same pool first."""
+    from ss25_hierarchical_multiscale_image_classification_amd import extract, train
+
+    slides = [extract.DeviceSlide.synthetic(5000, 4500, seed=71 + i, name=f"tumor_07{i}", with_polygons=True) for i in range(3)]
+    tl, vl, tds, vds, pool = train.get_device_loaders(slides, level=3, batch_size=8)
+    names = sorted(set(pool.slide_names))
+    assert len(names) == 3 and len(tds) > 0 and len(vds) > 0
+    tr_names = {pool.slide_names[i] for i in tds.indices}
+    va_names = {pool.slide_names[i] for i in vds.indices}
+    assert tr_names.isdisjoint(va_names) and len(va_names) == 1  # the reference's slide-level split (src/main.py:412-416)
+    c = vds.get_class_counts()
+    assert len(c) < 2 or c[0] == c[1]
+    model, hist = train.train_resnet_classifier(None, strategy="weighted_loss", epochs=1, batch_size=8, max_steps=2,
+                                                save_path=str(tmp_path / "clf.pth"), slides=slides, level=3)
+    assert len(hist) == 1 and np.isfinite(hist[0][0]) and (tmp_path / "clf.pth").exists()
+    model, hist = train.train_resnet_classifier(None, strategy="self_supervised", epochs=1, batch_size=8, max_steps=2, simclr_epochs=1,
+                                                simclr_path=str(tmp_path / "enc.pth"), save_path=str(tmp_path / "clf2.pth"),
+                                                slides=slides, level=3, simclr_precision="fp16")
+    assert (tmp_path / "enc.pth").exists() and (tmp_path / "clf2.pth").exists() and np.isfinite(hist[0][0])
