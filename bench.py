@@ -535,7 +535,11 @@ def run_simclr(args, rank, world, dev):
     One STEP = 2 x (1024 / N) views per rank; gradients are all-reduced over RCCL."""
     from ss25_hierarchical_multiscale_image_classification_amd import train_native
 
-    return train_native.bench_simclr_step(args, rank, world, dev)
+    rec = train_native.bench_simclr_step(args, rank, world, dev)
+    if world == 1:  # what feeds the step: both views made on the device from patches resident in HBM, next to the host's Pillow path
+        from ss25_hierarchical_multiscale_image_classification_amd import augment
+        rec["input_pipeline"] = augment.bench_input_pipeline(n_pairs=min(args.simclr_views, 1024), P=224, steps=5, device=dev)
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -156,18 +156,19 @@ __device__ __forceinline__ void hsv2rgb8(int h, int s, int v, int& r, int& g, in
 
 // colour operations of one view in LDS, then ToTensor / Normalize.  ops[4]: 0 brightness, 1 contrast, 2 saturation, 3 hue,
 // -1 none, applied in this order; out: float [view][3][224][224]
-__global__ __launch_bounds__(256) void aug_color_kernel(const unsigned char* __restrict__ img, const int* __restrict__ params,
+constexpr int kColorThreads = 1024;  // one workgroup per CU (LDS): 16 waves hide the hue step's fp64 latency
+__global__ __launch_bounds__(kColorThreads) void aug_color_kernel(const unsigned char* __restrict__ img, const int* __restrict__ params,
                                                         const float* __restrict__ lut, float* __restrict__ out,
                                                         unsigned char* __restrict__ out_u8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char px[];  // [224*224][3] then int red[4]
   constexpr int NPX = kOut * kOut;
-  int* red = reinterpret_cast<int*>(px + NPX * 3);
+  int* red = reinterpret_cast<int*>(px + NPX * 3);  // [kColorThreads / 64]
   const int v = blockIdx.x, tid = threadIdx.x;
   const int* pr = params + v * kAugParams;
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(img + (size_t)v * NPX * 3);  // 150528 bytes = 37632 dwords
     unsigned* dst = reinterpret_cast<unsigned*>(px);
-    for (int i = tid; i < NPX * 3 / 4; i += 256) dst[i] = src[i];
+    for (int i = tid; i < NPX * 3 / 4; i += kColorThreads) dst[i] = src[i];
   }
   __syncthreads();
   for (int o = 0; o < 4; ++o) {
@@ -179,16 +180,17 @@ __global__ __launch_bounds__(256) void aug_color_kernel(const unsigned char* __r
       int mean = 0;
       if (op == 1) {  // int(mean(L) + 0.5): the sum is exact, the tie-free rounding is integer arithmetic
         int s = 0;
-        for (int p = tid; p < NPX; p += 256) s += luma8(px[3 * p], px[3 * p + 1], px[3 * p + 2]);
+        for (int p = tid; p < NPX; p += kColorThreads) s += luma8(px[3 * p], px[3 * p + 1], px[3 * p + 2]);
         for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
         if ((tid & 63) == 0) red[tid >> 6] = s;
         __syncthreads();
-        const long long tot = (long long)red[0] + red[1] + red[2] + red[3];
+        long long tot = 0;
+        for (int wv = 0; wv < kColorThreads / 64; ++wv) tot += red[wv];
         mean = (int)((2 * tot + NPX) / (2 * NPX));
         __syncthreads();
       }
       const int interp = f >= 0.f && f <= 1.f;
-      for (int p = tid; p < NPX; p += 256) {
+      for (int p = tid; p < NPX; p += kColorThreads) {
         const int r = px[3 * p], g = px[3 * p + 1], b = px[3 * p + 2];
         int d0, d1, d2;
         if (op == 0) d0 = d1 = d2 = 0;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void aug_color_kernel(const unsigned char* __r
       }
     } else {  // hue: H += shift (uint8 wrap) in Pillow's HSV
       const int shift = pr[14] & 255;
-      for (int p = tid; p < NPX; p += 256) {
+      for (int p = tid; p < NPX; p += kColorThreads) {
         int uh, us, uv, r, g, b;
         rgb2hsv8(px[3 * p], px[3 * p + 1], px[3 * p + 2], uh, us, uv);
         hsv2rgb8((uh + shift) & 255, us, uv, r, g, b);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void aug_color_kernel(const unsigned char* __r
     __syncthreads();
   }
   if (pr[10]) {  // RandomGrayscale: L on all three channels
-    for (int p = tid; p < NPX; p += 256) {
+    for (int p = tid; p < NPX; p += kColorThreads) {
       const int l = luma8(px[3 * p], px[3 * p + 1], px[3 * p + 2]);
       px[3 * p] = px[3 * p + 1] = px[3 * p + 2] = (unsigned char)l;
     }
@@ -223,12 +225,12 @@ __global__ __launch_bounds__(256) void aug_color_kernel(const unsigned char* __r
   if (out_u8) {  // test tap: the augmented uint8 image
     unsigned* dst = reinterpret_cast<unsigned*>(out_u8 + (size_t)v * NPX * 3);
     const unsigned* s4 = reinterpret_cast<const unsigned*>(px);
-    for (int i = tid; i < NPX * 3 / 4; i += 256) dst[i] = s4[i];
+    for (int i = tid; i < NPX * 3 / 4; i += kColorThreads) dst[i] = s4[i];
   }
   if (out) {
     float* o = out + (size_t)v * 3 * NPX;
     for (int c = 0; c < 3; ++c)
-      for (int p = tid; p < NPX; p += 256) o[(size_t)c * NPX + p] = lut[c * 256 + px[3 * p + c]];
+      for (int p = tid; p < NPX; p += kColorThreads) o[(size_t)c * NPX + p] = lut[c * 256 + px[3 * p + c]];
   }
 }
 
@@ -275,7 +277,7 @@ int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, int geometry
   } else {
     hipLaunchKernelGGL(aug_affine_kernel, gv, dim3(256), 0, s, pool, params, crops);
   }
-  constexpr int LDS = kOut * kOut * 3 + 64;
+  constexpr int LDS = kOut * kOut * 3 + kColorThreads / 64 * 4;
   static bool attr_done[64] = {};
   {
     int dev = 0;
@@ -285,7 +287,7 @@ int hipac_augment_views(const uint8_t* pool, int64_t n_pool, int P, int geometry
       if (dev >= 0) attr_done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(aug_color_kernel, dim3((unsigned)n_views), dim3(256), LDS, s, (const unsigned char*)crops, params, lut, out,
+  hipLaunchKernelGGL(aug_color_kernel, dim3((unsigned)n_views), dim3(kColorThreads), LDS, s, (const unsigned char*)crops, params, lut, out,
                      out_u8);
   HIPAC_CHECK_HIP(hipGetLastError());
   return 0;
