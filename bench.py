@@ -246,8 +246,13 @@ def scan_slide_timed(net, slide, args, world, steps, warmup, dev):
             f, l, meta = hdist.gather_results(f, l, meta)
         return n_local
 
-    for _ in range(warmup):
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for i in range(warmup):
         step()
+        if i == 0:  # the first scan of a slide: + the annotation mask raster (host, Pillow), the window tables, first allocations
+            torch.cuda.synchronize()
+            scan_slide_timed.cold_s = time.perf_counter() - t_cold
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -278,6 +283,7 @@ def wsi_object(net, args, rank, world, dev, sides):
             slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
             s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, steps=2, warmup=1, dev=dev)
             rec = {"s_per_slide": s_per, "scans_s": [round(t, 4) for t in getattr(scan_slide_timed, "last_scans", [])],
+                   "first_scan_s": round(getattr(scan_slide_timed, "cold_s", float("nan")), 4),
                    "windows": n_all, "kept": n_kept, "n_gpus": world, "slides": world,
                    "kept_patches_per_s": world * n_kept / s_per if world == 1 else None,
                    "unique_source_GBps": world * sum(w * h * 3 for (w, h) in slide.level_dimensions) / s_per / 1e9}

@@ -80,6 +80,37 @@ def rasterize_mask(polygons_l0, level_dims: Tuple[int, int], base_dims: Tuple[in
     return np.array(mask)
 
 
+def rasterize_mask_bands(polygons_l0, level_dims: Tuple[int, int], base_dims: Tuple[int, int], band: int = 2048, margin: int = 2):
+    """The same mask as ``rasterize_mask``, produced in horizontal bands and ONLY where a polygon reaches: yields
+    (first row, uint8[rows, W]) for every band some polygon intersects -- all other rows of the mask are zero.  A band is
+    drawn on an image of its own height (+ ``margin`` rows above and below, discarded) with the polygons translated in y:
+    Pillow's scanline fill computes its crossings as (y - y0) * dx + x0, which a translation in y leaves bit for bit, and
+    the margin keeps the band's own clipping away from the rows that are kept (tests/test_host_logic.py compares with the
+    full-size raster, vertices on band boundaries included).  At level 0 of a 100 000^2 slide the full raster is a 10 GB
+    host image (allocate, fill, convert, upload: ~11 s); the bands touch only the annotated rows."""
+    from PIL import Image, ImageDraw
+
+    W, H = level_dims
+    sx, sy = level_dims[0] / base_dims[0], level_dims[1] / base_dims[1]
+    polys = []
+    for poly in polygons_l0:
+        pts = [(int(float(x) * sx), int(float(y) * sy)) for x, y in poly]
+        if pts:
+            ys = [y for _, y in pts]
+            polys.append((pts, min(ys), max(ys)))
+    for b0 in range(0, H, band):
+        b1 = min(H, b0 + band)
+        t0, t1 = b0 - margin, b1 + margin
+        sel = [pts for pts, lo, hi in polys if hi >= t0 and lo < t1]
+        if not sel:
+            continue
+        img = Image.new("L", (W, t1 - t0), 0)
+        draw = ImageDraw.Draw(img)
+        for pts in sel:
+            draw.polygon([(x, y - t0) for x, y in pts], outline=255, fill=255)
+        yield b0, np.asarray(img)[margin:margin + (b1 - b0)]
+
+
 class DeviceSlide:
     """A slide pyramid resident in HBM: per level a uint8[H, Wpad, 3] tensor whose row
     pitch is a multiple of 48 bytes (16 pixels) so the preprocess kernel can use
@@ -139,11 +170,12 @@ class DeviceSlide:
         if self.polygons is None:
             return None
         if level not in self._masks:
-            m = rasterize_mask(self.polygons, self.level_dimensions[level], self.level_dimensions[0])
-            h, w = m.shape
+            w, h = self.level_dimensions[level]
             wp = (w + 15) // 16 * 16  # zero-padded row pitch: 16-byte loads in hipac_mask_cells
             buf = torch.zeros((h, wp), dtype=torch.uint8, device=self.device)
-            buf[:, :w] = torch.from_numpy(m).to(self.device)
+            # Pillow's raster (the reference's, src/main.py:387-410) band by band, only where a polygon reaches
+            for y0, rows in rasterize_mask_bands(self.polygons, (w, h), self.level_dimensions[0]):
+                buf[y0:y0 + rows.shape[0], :w] = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
             self._masks[level] = buf
         return self._masks[level]
 

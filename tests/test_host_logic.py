@@ -206,3 +206,34 @@ def test_device_view_parameters_take_the_host_transforms_draws():
             assert sorted(row[6:10]) == [0, 1, 2, 3]
             b, c, s = (float(np.int32(v).view(np.float32)) for v in row[11:14])
             assert 0.6 <= b <= 1.4 and 0.6 <= c <= 1.4 and 0.6 <= s <= 1.4 and (row[14] <= 25 or row[14] >= 231)
+
+
+def test_banded_mask_raster_equals_the_full_raster():
+    """extract.rasterize_mask_bands (what DeviceSlide.mask uploads) against rasterize_mask (one full-size Pillow image, the
+    reference's arrangement, src/main.py:387-410): same bytes -- polygons crossing bands, vertices on band boundaries,
+    horizontal edges, polygons partly outside the level."""
+    from ss25_hierarchical_multiscale_image_classification_amd import extract
+
+    rng = np.random.default_rng(4)
+    for trial in range(60):
+        W, H = int(rng.integers(300, 1400)), int(rng.integers(400, 2200))
+        base = (4 * W + int(rng.integers(0, 4)), 4 * H + int(rng.integers(0, 4)))
+        polys = []
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.integers(3, 30))
+            cx, cy, r = rng.integers(-400, base[0] + 400), rng.integers(-400, base[1] + 400), rng.integers(20, 3600)
+            if rng.random() < 0.5:
+                ang, rad = np.sort(rng.uniform(0, 2 * np.pi, n)), r * rng.uniform(0.3, 1.0, n)
+                pts = [(float(cx + a * np.cos(t)), float(cy + a * np.sin(t))) for a, t in zip(rad, ang)]
+            else:
+                pts = [(float(cx + rng.integers(-r, r + 1)), float(cy + rng.integers(-r, r + 1))) for _ in range(n)]
+            if rng.random() < 0.4:  # vertices that land on (or next to) band boundaries after scaling; horizontal edges
+                pts = [(x, float((int(y) // 512) * 512 + int(rng.integers(-4, 5)))) if rng.random() < 0.5 else (x, y) for x, y in pts]
+            polys.append(pts)
+        ref = extract.rasterize_mask(polys, (W, H), base)
+        for band, margin in ((128, 2), (97, 2), (2048, 2)):
+            got = np.zeros_like(ref)
+            for y0, rows in extract.rasterize_mask_bands(polys, (W, H), base, band=band, margin=margin):
+                got[y0:y0 + rows.shape[0]] = rows
+            assert np.array_equal(got, ref), (trial, band)
+    assert list(extract.rasterize_mask_bands([], (100, 100), (400, 400))) == []
