@@ -81,13 +81,15 @@ def rasterize_mask(polygons_l0, level_dims: Tuple[int, int], base_dims: Tuple[in
 
 
 def rasterize_mask_bands(polygons_l0, level_dims: Tuple[int, int], base_dims: Tuple[int, int], band: int = 2048, margin: int = 2):
-    """The same mask as ``rasterize_mask``, produced in horizontal bands and ONLY where a polygon reaches: yields
-    (first row, uint8[rows, W]) for every band some polygon intersects -- all other rows of the mask are zero.  A band is
-    drawn on an image of its own height (+ ``margin`` rows above and below, discarded) with the polygons translated in y:
-    Pillow's scanline fill computes its crossings as (y - y0) * dx + x0, which a translation in y leaves bit for bit, and
-    the margin keeps the band's own clipping away from the rows that are kept (tests/test_host_logic.py compares with the
-    full-size raster, vertices on band boundaries included).  At level 0 of a 100 000^2 slide the full raster is a 10 GB
-    host image (allocate, fill, convert, upload: ~11 s); the bands touch only the annotated rows."""
+    """The same mask as ``rasterize_mask``, produced ONLY where a polygon reaches: yields (first row, first column,
+    uint8[rows, cols]) pieces -- every other byte of the mask is zero.  The rows that polygons touch are cut into bands of at
+    most ``band`` rows; a band is drawn on an image of its own height (+ ``margin`` rows above and below, discarded) with the
+    polygons translated in y: Pillow's scanline fill computes its crossings as (y - y0) * dx + x0, which a translation in
+    y leaves bit for bit, and the margin keeps the band's own clipping away from the rows that are kept.  In x nothing is
+    translated (x0 enters a float32 sum): the canvas starts at column 0 and merely ends behind the band's rightmost vertex;
+    only the columns between the leftmost and the rightmost vertex are returned.  tests/test_host_logic.py compares with
+    the full-size raster (vertices on band boundaries included).  At level 0 of a 100 000^2 slide the full raster is a
+    10 GB host image (allocate, fill, convert, upload: ~11 s)."""
     from PIL import Image, ImageDraw
 
     W, H = level_dims
@@ -96,19 +98,32 @@ def rasterize_mask_bands(polygons_l0, level_dims: Tuple[int, int], base_dims: Tu
     for poly in polygons_l0:
         pts = [(int(float(x) * sx), int(float(y) * sy)) for x, y in poly]
         if pts:
-            ys = [y for _, y in pts]
-            polys.append((pts, min(ys), max(ys)))
-    for b0 in range(0, H, band):
-        b1 = min(H, b0 + band)
-        t0, t1 = b0 - margin, b1 + margin
-        sel = [pts for pts, lo, hi in polys if hi >= t0 and lo < t1]
-        if not sel:
-            continue
-        img = Image.new("L", (W, t1 - t0), 0)
-        draw = ImageDraw.Draw(img)
-        for pts in sel:
-            draw.polygon([(x, y - t0) for x, y in pts], outline=255, fill=255)
-        yield b0, np.asarray(img)[margin:margin + (b1 - b0)]
+            xs, ys = [x for x, _ in pts], [y for _, y in pts]
+            polys.append((pts, min(ys), max(ys), min(xs), max(xs)))
+    # rows any polygon touches, merged into runs, runs cut into bands
+    spans = sorted((max(0, lo), min(H, hi + 1)) for _, lo, hi, _, _ in polys if hi >= 0 and lo < H)
+    runs = []
+    for lo, hi in spans:
+        if runs and lo <= runs[-1][1]:
+            runs[-1][1] = max(runs[-1][1], hi)
+        else:
+            runs.append([lo, hi])
+    for r0, r1 in runs:
+        for b0 in range(r0, r1, band):
+            b1 = min(r1, b0 + band)
+            t0, t1 = b0 - margin, b1 + margin
+            sel = [(pts, x0, x1) for pts, lo, hi, x0, x1 in polys if hi >= t0 and lo < t1]
+            if not sel:
+                continue
+            c0 = max(0, min(x0 for _, x0, _ in sel))
+            c1 = min(W, max(x1 for _, _, x1 in sel) + 1)
+            if c1 <= c0:
+                continue  # entirely left or right of the level
+            img = Image.new("L", (min(W, c1 + 1), t1 - t0), 0)
+            draw = ImageDraw.Draw(img)
+            for pts, _, _ in sel:
+                draw.polygon([(x, y - t0) for x, y in pts], outline=255, fill=255)
+            yield b0, c0, np.asarray(img)[margin:margin + (b1 - b0), c0:c1]
 
 
 class DeviceSlide:
@@ -174,8 +189,8 @@ class DeviceSlide:
             wp = (w + 15) // 16 * 16  # zero-padded row pitch: 16-byte loads in hipac_mask_cells
             buf = torch.zeros((h, wp), dtype=torch.uint8, device=self.device)
             # Pillow's raster (the reference's, src/main.py:387-410) band by band, only where a polygon reaches
-            for y0, rows in rasterize_mask_bands(self.polygons, (w, h), self.level_dimensions[0]):
-                buf[y0:y0 + rows.shape[0], :w] = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
+            for y0, x0, piece in rasterize_mask_bands(self.polygons, (w, h), self.level_dimensions[0]):
+                buf[y0:y0 + piece.shape[0], x0:x0 + piece.shape[1]] = torch.from_numpy(np.ascontiguousarray(piece)).to(self.device)
             self._masks[level] = buf
         return self._masks[level]
 

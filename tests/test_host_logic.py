@@ -233,7 +233,8 @@ def test_banded_mask_raster_equals_the_full_raster():
         ref = extract.rasterize_mask(polys, (W, H), base)
         for band, margin in ((128, 2), (97, 2), (2048, 2)):
             got = np.zeros_like(ref)
-            for y0, rows in extract.rasterize_mask_bands(polys, (W, H), base, band=band, margin=margin):
-                got[y0:y0 + rows.shape[0]] = rows
+            for y0, x0, piece in extract.rasterize_mask_bands(polys, (W, H), base, band=band, margin=margin):
+                assert not got[y0:y0 + piece.shape[0], x0:x0 + piece.shape[1]].any()  # pieces do not overlap
+                got[y0:y0 + piece.shape[0], x0:x0 + piece.shape[1]] = piece
             assert np.array_equal(got, ref), (trial, band)
     assert list(extract.rasterize_mask_bands([], (100, 100), (400, 400))) == []
