@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define HIPAC_ABI_VERSION 5  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3; 4: hipac_train_amp_*; 5: hipac_augment_views */
+#define HIPAC_ABI_VERSION 6  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3; 4: hipac_train_amp_*; 5: hipac_augment_views; 6: hipac_jpeg_decode_tiles */
 
 /* error codes (positive small values are hipError_t) */
 #define HIPAC_EINVAL (-1)     /* bad argument (shape, enum, null pointer, alignment) */
@@ -338,6 +338,36 @@ int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, i
                                      void* workspace, size_t workspace_bytes, void* stream);
 /* grads[i] *= inv_scale; found_inf[0] (device int32, zeroed by the caller) becomes 1 when a gradient is inf / nan. */
 int hipac_grads_unscale_check(float* grads, int64_t n, float inv_scale, int32_t* found_inf, void* stream);
+
+/* Baseline-JPEG tiles of a tiled pyramidal TIFF decoded on the device, straight into a level image in HBM -- what
+ * openslide.OpenSlide(path) / read_region do with libjpeg on the host for the reference (src/main.py:650, :693).
+ * Huffman decoding runs one lane per TILE, then libjpeg's integer ("ISLOW") IDCT, its h2v2 "fancy" chroma upsampling and
+ * its fixed-point YCbCr -> RGB: bit-exact against libjpeg / Pillow.  Supported per tile: baseline sequential, 8 bit, 3
+ * components in one interleaved scan, 4:2:0 or 4:4:4, Huffman table ids 0 / 1, JPEG size == tile size, tile sides multiples
+ * of 16; every other tile is left untouched and reported in `status_host` so the caller decodes it on the host.
+ *   file_host / file_dev : the file's bytes in HOST memory (headers are parsed there) and the same bytes in DEVICE memory
+ *                          (16 readable bytes behind the end)
+ *   levels               : HOST hipac_jpeg_level[n_levels]: where the tiles of a level go (DEVICE uint8[H][pitch_bytes] RGB,
+ *                          W x H pixels; tiles are clipped to it), its tile size, its JPEGTables tag (347; HOST bytes or NULL)
+ *                          and its photometric tag (262: 6 = YCbCr, converted to RGB; 2 = RGB samples in the stream)
+ *   tile_off, tile_len   : HOST int64[n_tiles] TileOffsets / TileByteCounts (len 0 = missing tile)
+ *   tile_xyl             : HOST int32[n_tiles][3]: destination (x, y) of the tile's top-left pixel, index into `levels` --
+ *                          tiles of ALL levels go into one call: a lane's walk through its tile is serial, so the time of a
+ *                          call is the time of its slowest tile and the levels should share it
+ *   workspace            : DEVICE scratch of hipac_jpeg_workspace_bytes(largest tile_w, tile_h, n_tiles) bytes
+ *   status_host          : HOST uint8[n_tiles]: 0 decoded here, 1 not supported (decode on the host), 2 missing tile
+ * n_tiles <= 65535 per call, n_levels <= 64.  The call returns when its kernels have finished. */
+typedef struct {
+  uint8_t* pixels;
+  int64_t pitch_bytes;
+  int32_t W, H, tile_w, tile_h, photometric, reserved;
+  const uint8_t* jpeg_tables;
+  int64_t jpeg_tables_len;
+} hipac_jpeg_level;
+size_t hipac_jpeg_workspace_bytes(int tile_w, int tile_h, int n_tiles);
+int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, int64_t file_bytes, const hipac_jpeg_level* levels,
+                            int n_levels, const int64_t* tile_off, const int64_t* tile_len, const int32_t* tile_xyl, int n_tiles,
+                            void* workspace, size_t workspace_bytes, uint8_t* status_host, void* stream);
 
 /* Training-view augmentation on patches resident in HBM -- replaces, per view, torchvision's PIL pipelines
  *   geometry 0 (SimCLR): RandomResizedCrop(224) / RandomHorizontalFlip / RandomApply([ColorJitter(.4,.4,.4,.1)], .8) /

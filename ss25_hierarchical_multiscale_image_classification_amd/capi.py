@@ -23,7 +23,7 @@ PREC_BF16, PREC_FP16, PREC_FP32, PREC_FP16X3 = 0, 1, 2, 3
 IN_NCHW_F32, IN_NHWC4_PAD, IN_U8_HWC = 0, 1, 2
 OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
 PATCH, PAD_H, PAD_W = 224, 230, 232
-ABI_VERSION = 5  # include/hipac.h HIPAC_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/hipac.h HIPAC_ABI_VERSION this binding was written against
 
 # "fp16x3" is the parity mode (fp16 (hi, lo) pairs, three MFMA products per term: the reference's fp32 results to 1e-3);
 # "fp32" the debugging reference: fp32 storage and the exact f32 MFMA (about 1/16 of the bf16 rate)
@@ -37,6 +37,13 @@ class HipacError(RuntimeError):
 
 class ConvBN(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("conv_w", "bn_gamma", "bn_beta", "bn_mean", "bn_var")]
+
+
+class JpegLevel(C.Structure):
+    """hipac_jpeg_level (include/hipac.h)."""
+    _fields_ = [("pixels", C.c_void_p), ("pitch_bytes", C.c_int64), ("W", C.c_int32), ("H", C.c_int32), ("tile_w", C.c_int32),
+                ("tile_h", C.c_int32), ("photometric", C.c_int32), ("reserved", C.c_int32), ("jpeg_tables", C.c_void_p),
+                ("jpeg_tables_len", C.c_int64)]
 
 
 class MilParams(C.Structure):  # hipac_mil_params_t
@@ -118,6 +125,9 @@ SYMBOLS = {
     "hipac_train_amp_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                                    C.c_void_p]),
     "hipac_grads_unscale_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "hipac_jpeg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hipac_jpeg_decode_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "hipac_augment_views": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hipac_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

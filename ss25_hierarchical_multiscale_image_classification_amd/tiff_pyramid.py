@@ -211,17 +211,90 @@ class TiffPyramid:
         return out
 
     # ---- device pyramid ----------------------------------------------------------------
-    def to_device_levels(self, device="cuda", levels: Optional[Sequence[int]] = None, workers: int = 16):
-        """Decode on host threads, band by band, into uint8[H, Wpad, 3] HBM tensors (row pitch a multiple
-        of 16 pixels, as ``DeviceSlide`` lays levels out).  Returns a list of (tensor, width)."""
+    def _device_jpeg_levels(self, lvs, devs, chunk_bytes: int = 6 << 30):
+        """JPEG tiles of the given levels decoded on the device (csrc/jpeg_decode.hip: Huffman one lane per tile, libjpeg's
+        integer IDCT, fancy upsampling, YCbCr -> RGB), written into ``devs`` (uint8[H, Wpad, 3] each).  The tiles of ALL levels
+        go into the same calls (a call lasts as long as its slowest tile).  Returns, per level, the indices of the tiles the
+        device decoder did not take (another sampling, progressive, ...): the caller decodes those on the host."""
+        import ctypes as C
+
+        import torch
+
+        from . import capi
+
+        lib = capi.load_library()
+        device = devs[0].device
+        file_dev = torch.empty(int(self._mm.shape[0]) + 64, dtype=torch.uint8, device=device)  # + slack behind the end
+        file_dev[:self._mm.shape[0]] = torch.from_numpy(np.array(self._mm, copy=True)).to(device)
+        tabs = [np.frombuffer(bytes(lv.jpeg_tables), np.uint8) if lv.jpeg_tables else None for lv in lvs]
+        arr = (capi.JpegLevel * len(lvs))()
+        for i, (lv, dv) in enumerate(zip(lvs, devs)):
+            arr[i] = capi.JpegLevel(dv.data_ptr(), int(dv.stride(0)), lv.width, lv.height, lv.tile_w, lv.tile_h, int(lv.photometric), 0,
+                                    tabs[i].ctypes.data if tabs[i] is not None else None, int(tabs[i].shape[0]) if tabs[i] is not None else 0)
+        off, cnt, xyl, lvl_of, idx_of = [], [], [], [], []
+        for i, lv in enumerate(lvs):
+            n = lv.tiles_across * lv.tiles_down
+            k = np.arange(n)
+            off.append(np.asarray(lv.offsets[:n], np.int64)), cnt.append(np.asarray(lv.counts[:n], np.int64))
+            xyl.append(np.stack([(k % lv.tiles_across) * lv.tile_w, (k // lv.tiles_across) * lv.tile_h, np.full(n, i)], 1).astype(np.int32))
+            lvl_of.append(np.full(n, i)), idx_of.append(k)
+        off, cnt, xyl = np.concatenate(off), np.concatenate(cnt), np.concatenate(xyl)
+        lvl_of, idx_of = np.concatenate(lvl_of), np.concatenate(idx_of)
+        n = off.shape[0]
+        tw, th = max(lv.tile_w for lv in lvs), max(lv.tile_h for lv in lvs)
+        per_tile = lib.hipac_jpeg_workspace_bytes(tw, th, 1)
+        step = int(max(1, min(32768, chunk_bytes // max(per_tile, 1))))
+        ws = torch.empty(lib.hipac_jpeg_workspace_bytes(tw, th, min(step, n)), dtype=torch.uint8, device=device)
+        left = [[] for _ in lvs]
+        with torch.cuda.device(device):
+            for i0 in range(0, n, step):
+                m = min(step, n - i0)
+                status = np.ones(m, np.uint8)
+                o, c, q = np.ascontiguousarray(off[i0:i0 + m]), np.ascontiguousarray(cnt[i0:i0 + m]), np.ascontiguousarray(xyl[i0:i0 + m])
+                capi._check(lib.hipac_jpeg_decode_tiles(self._mm.ctypes.data, file_dev.data_ptr(), int(self._mm.shape[0]), C.addressof(arr),
+                                                        len(lvs), o.ctypes.data, c.ctypes.data, q.ctypes.data, m, ws.data_ptr(),
+                                                        int(ws.numel()), status.ctypes.data, capi._stream()), "hipac_jpeg_decode_tiles")
+                for k in np.nonzero(status == 1)[0]:
+                    left[int(lvl_of[i0 + k])].append(int(idx_of[i0 + k]))
+                self.device_decoded = getattr(self, "device_decoded", 0) + int((status == 0).sum())
+        return left
+
+    def to_device_levels(self, device="cuda", levels: Optional[Sequence[int]] = None, workers: int = 16,
+                         device_jpeg: Optional[bool] = None):
+        """Into uint8[H, Wpad, 3] HBM tensors (row pitch a multiple of 16 pixels, as ``DeviceSlide`` lays levels out).
+        JPEG levels on a ROCm device: the compressed file goes to HBM once and the tiles are decoded there
+        (``_device_jpeg_levels``; ``device_jpeg=False`` or ``HIPAC_DEVICE_JPEG=0`` keeps the host decoder); tiles the device
+        decoder does not take, and the other compressions, are decoded on host threads and copied band by band.
+        Returns a list of (tensor, width)."""
+        import os
+
         import torch
 
         out = []
+        use_dev = (device_jpeg if device_jpeg is not None else os.environ.get("HIPAC_DEVICE_JPEG", "1") != "0") and \
+            torch.device(device).type == "cuda"
+        use = list(range(self.level_count) if levels is None else levels)
+        bufs = {}
+        for li in use:
+            lv = self.levels[li]
+            bufs[li] = torch.zeros((lv.height, (lv.width + 15) // 16 * 16, 3), dtype=torch.uint8, device=device)
+        on_dev = [li for li in use if use_dev and self.levels[li].compression == 7 and self.levels[li].samples == 3]
+        left = dict(zip(on_dev, self._device_jpeg_levels([self.levels[li] for li in on_dev], [bufs[li] for li in on_dev]))) if on_dev else {}
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            for li in (range(self.level_count) if levels is None else levels):
+            for li in use:
                 lv = self.levels[li]
-                wp = (lv.width + 15) // 16 * 16
-                dev = torch.zeros((lv.height, wp, 3), dtype=torch.uint8, device=device)
+                dev = bufs[li]
+                if li in left:
+                    todo = left[li]
+                    for idx, t in zip(todo, pool.map(lambda i: self._decode_tile(lv, i), todo)):
+                        if t is None:
+                            continue
+                        ty, tx = divmod(idx, lv.tiles_across)
+                        y0, x0 = ty * lv.tile_h, tx * lv.tile_w
+                        rows, cols = min(lv.tile_h, lv.height - y0), min(lv.tile_w, lv.width - x0)
+                        dev[y0:y0 + rows, x0:x0 + cols] = torch.from_numpy(np.ascontiguousarray(t[:rows, :cols])).to(device)
+                    out.append((dev, lv.width))
+                    continue
                 for tr in range(lv.tiles_down):
                     band = torch.from_numpy(self.read_band(li, tr, pool))
                     if dev.is_cuda:
@@ -257,7 +330,7 @@ def _split_jpeg_tables(data: bytes) -> Tuple[bytes, bytes]:
 
 def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, compression: str = "jpeg",
                      quality: int = 90, bigtiff: bool = False, missing: Sequence[Tuple[int, int, int]] = (),
-                     jpeg_tables: bool = False):
+                     jpeg_tables: bool = False, subsampling: int = -1, jpeg_options: Optional[dict] = None):
     """Minimal writer of a tiled pyramid (tests and synthetic data only): ``levels`` are uint8[H,W,3]
     arrays, largest first.  compression: "none" | "deflate" | "jpeg" (YCbCr; every tile a complete JPEG, or with
     ``jpeg_tables=True`` abbreviated streams plus one JPEGTables tag per directory, as real slide files have
@@ -288,7 +361,7 @@ def write_tiled_tiff(path: str, levels: Sequence[np.ndarray], tile: int = 256, c
                     data = zlib.compress(t.tobytes(), 6)
                 else:
                     bio = io.BytesIO()
-                    Image.fromarray(t, "RGB").save(bio, "JPEG", quality=quality)
+                    Image.fromarray(t, "RGB").save(bio, "JPEG", quality=quality, subsampling=subsampling, **(jpeg_options or {}))
                     data = bio.getvalue()
                     if jpeg_tables:  # fixed quality, default Huffman tables: every tile shares one set
                         tb, data = _split_jpeg_tables(data)
