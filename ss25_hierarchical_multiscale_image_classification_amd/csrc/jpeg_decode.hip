@@ -497,6 +497,12 @@ int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, i
   std::vector<JpegCfg> cfgs;
   std::vector<TileDesc> descs;
   std::vector<int> which;  // tile index of every descriptor
+  // consecutive tiles of a level nearly always carry the same tables and frame: remember the last ones and their configuration
+  HostTables last_T;
+  HostFrame last_F;
+  int last_lvl = -1, last_ci = -1;
+  std::memset(&last_T, 0, sizeof(last_T));
+  std::memset(&last_F, 0, sizeof(last_F));
   for (int t = 0; t < n_tiles; ++t) {
     status_host[t] = 1;
     const long long off = tile_off[t], len = tile_len[t];
@@ -517,6 +523,15 @@ int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, i
     F.scan = -1, F.adobe = -1;
     if (parse_stream(file_host + off, len, T, F) != 0 || F.scan < 0) continue;
     if (F.w != tile_w || F.h != tile_h) continue;
+    {
+      HostFrame Fs = F;
+      Fs.scan = 0;  // the scan offset differs per tile, the rest of the frame decides the configuration
+      if (last_ci >= 0 && lvl == last_lvl && std::memcmp(&Fs, &last_F, sizeof(Fs)) == 0 && std::memcmp(&T, &last_T, sizeof(T)) == 0) {
+        descs.push_back(TileDesc{off + F.scan, off + len, last_ci, tile_xyl[3 * t], tile_xyl[3 * t + 1], lvl});
+        which.push_back(t);
+        continue;
+      }
+    }
     const bool s420 = F.hs[0] == 2 && F.vs[0] == 2 && F.hs[1] == 1 && F.vs[1] == 1 && F.hs[2] == 1 && F.vs[2] == 1;
     const bool s444 = F.hs[0] == 1 && F.vs[0] == 1 && F.hs[1] == 1 && F.vs[1] == 1 && F.hs[2] == 1 && F.vs[2] == 1;
     if (!s420 && !s444) continue;
@@ -558,6 +573,7 @@ int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, i
     }
     descs.push_back(TileDesc{off + F.scan, off + len, ci, tile_xyl[3 * t], tile_xyl[3 * t + 1], lvl});
     which.push_back(t);
+    last_T = T, last_F = F, last_F.scan = 0, last_lvl = lvl, last_ci = ci;
   }
   const int nd = (int)descs.size();
   if (nd == 0) return 0;

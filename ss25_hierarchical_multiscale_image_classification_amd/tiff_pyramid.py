@@ -211,7 +211,7 @@ class TiffPyramid:
         return out
 
     # ---- device pyramid ----------------------------------------------------------------
-    def _device_jpeg_levels(self, lvs, devs, chunk_bytes: int = 6 << 30):
+    def _device_jpeg_levels(self, lvs, devs, chunk_bytes: Optional[int] = None):
         """JPEG tiles of the given levels decoded on the device (csrc/jpeg_decode.hip: Huffman one lane per tile, libjpeg's
         integer IDCT, fancy upsampling, YCbCr -> RGB), written into ``devs`` (uint8[H, Wpad, 3] each).  The tiles of ALL levels
         go into the same calls (a call lasts as long as its slowest tile).  Returns, per level, the indices of the tiles the
@@ -224,8 +224,15 @@ class TiffPyramid:
 
         lib = capi.load_library()
         device = devs[0].device
+        import warnings
+
         file_dev = torch.empty(int(self._mm.shape[0]) + 64, dtype=torch.uint8, device=device)  # + slack behind the end
-        file_dev[:self._mm.shape[0]] = torch.from_numpy(np.array(self._mm, copy=True)).to(device)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # "the given NumPy array is not writable": it is only read
+            file_dev[:self._mm.shape[0]].copy_(torch.from_numpy(self._mm))
+        if chunk_bytes is None:  # scratch for as many tiles per call as HBM allows: a call lasts as long as its slowest tile
+            free, _ = torch.cuda.mem_get_info(device)
+            chunk_bytes = int(max(1 << 30, min(96 << 30, free // 2)))
         tabs = [np.frombuffer(bytes(lv.jpeg_tables), np.uint8) if lv.jpeg_tables else None for lv in lvs]
         arr = (capi.JpegLevel * len(lvs))()
         for i, (lv, dv) in enumerate(zip(lvs, devs)):
