@@ -16,7 +16,8 @@
 // (tests/test_gpu_jpeg.py; the formulas were first pinned by a pure-Python restatement on the CPU).  Supported: baseline
 // sequential, 8 bit, three components, 4:2:0 or 4:4:4, Huffman table ids 0 / 1, tile sides that are multiples of 16;
 // anything else is reported per tile (status 1) and the caller decodes that tile on the host as before.  Bound: the Huffman
-// kernel's serial bit walk per lane (latency, not HBM).
+// kernel's serial bit walk per lane (~2 us per symbol in SIMT -- 64-bit buffer arithmetic on a 32-bit ALU, an LDS look-up and
+// a handful of two-sided branches per symbol; 95 % of a load, its coefficient stores are 5 % of it): latency, not HBM.
 #include "common.h"
 
 #include <cstring>
@@ -95,9 +96,25 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   int n = 0;
   int pred0 = 0, pred1 = 0, pred2 = 0;
   const int dri = c.dri, mcus_x = c.mcus_x, n_mcus = c.mcus_x * c.mcus_y, mcu_blocks = c.mcu_blocks;
+  // everything the walk needs from the configuration lives in registers: a load from it would sit in the dependent chain
+  // of every symbol (one wave per SIMD at best: nothing hides a latency here)
+  unsigned long long mcu_pack = 0;  // per block of the MCU: component (2 bits), row (1), column (1)
+  for (int b = 0; b < mcu_blocks; ++b)
+    mcu_pack |= (unsigned long long)(c.mcu_ci[b] | (c.mcu_by[b] << 2) | (c.mcu_bx[b] << 3)) << (4 * b);
+  unsigned tab_pack = 0;  // per component: DC table id (bit 0), AC table id (bit 1)
+  for (int q = 0; q < 3; ++q) tab_pack |= (unsigned)(c.td[q] | (c.ta[q] << 1)) << (2 * q);
+  const int hs0 = c.hs[0], vs0 = c.vs[0], bw0 = c.bw[0], bw1 = c.bw[1], bo1 = c.blk_off[1], bo2 = c.blk_off[2];
+  auto block_ptr = [&](int bi_, int mx_, int my_, int& ci_) -> short* {
+    const int e = (int)(mcu_pack >> (4 * bi_)) & 15;
+    ci_ = e & 3;
+    const int by = (e >> 2) & 1, bx = (e >> 3) & 1;
+    // component 0 has (hs0, vs0) blocks per MCU, the chroma components one
+    const size_t b = ci_ == 0 ? (size_t)(my_ * vs0 + by) * bw0 + mx_ * hs0 + bx : (size_t)(ci_ == 1 ? bo1 : bo2) + (size_t)my_ * bw1 + mx_;
+    return out + b * 64;
+  };
   int m = 0, mx = 0, my = 0, bi = 0, left = dri, k = 0;
-  int ci = c.mcu_ci[0];
-  short* blk = out + ((size_t)c.blk_off[ci] + (size_t)(my * c.vs[ci] + c.mcu_by[0]) * c.bw[ci] + mx * c.hs[ci] + c.mcu_bx[0]) * 64;
+  int ci;
+  short* blk = block_ptr(0, 0, 0, ci);
   while (m < n_mcus) {
     // ---- at least 32 bits (a code is <= 16 bits, its extra bits <= 15)
     if (n < 32) {
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
     }
     // ---- one symbol
     const bool is_dc = k == 0;
-    const int tid_dc = c.td[ci], tid_ac = c.ta[ci];
+    const int tid_dc = (int)(tab_pack >> (2 * ci)) & 1, tid_ac = (int)(tab_pack >> (2 * ci + 1)) & 1;
     const DevHuff& tb = shared_tables ? sh[is_dc ? tid_dc : 2 + tid_ac] : (is_dc ? c.dc[tid_dc] : c.ac[tid_ac]);
     int sym;
     {
@@ -192,8 +209,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
           left = dri;
         }
       }
-      ci = c.mcu_ci[bi];
-      blk = out + ((size_t)c.blk_off[ci] + (size_t)(my * c.vs[ci] + c.mcu_by[bi]) * c.bw[ci] + mx * c.hs[ci] + c.mcu_bx[bi]) * 64;
+      blk = block_ptr(bi, mx, my, ci);
     }
   }
 }
