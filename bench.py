@@ -428,6 +428,8 @@ def run_resnet(args, rank, world, dev):
             except (RuntimeError, capi.HipacError) as e:
                 w["parity_mode"] = {"error": str(e)[:300]}
             torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not args.no_tiff:
+            w["tiff_ingest"] = tiff_ingest_object(dev)
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
                 w["cpu_baseline"] = cpu_baseline_wsi()
@@ -469,6 +471,45 @@ def run_resnet(args, rank, world, dev):
             rec["simclr"] = obj
         torch.cuda.empty_cache()
     return rec
+
+
+def tiff_ingest_object(dev, side=20000):
+    """How a slide FILE gets into HBM: a synthetic `side`^2 pyramid written as a tiled TIFF with JPEG tiles (512 x 512, 4:2:0, one
+    JPEGTables set per level -- the CAMELYON16 layout), loaded with the tiles decoded on the device (hipac_jpeg_decode_tiles) and,
+    for comparison, on the host's threads (Pillow / libjpeg-turbo).  Both give the same bytes (tests/test_gpu_jpeg.py)."""
+    import tempfile
+
+    from ss25_hierarchical_multiscale_image_classification_amd import extract, tiff_pyramid
+
+    try:
+        l0 = synth.synth_level0(side, side, seed=2, device=dev)
+        levels = [t.cpu().numpy() for t in synth.build_pyramid(l0, 4)]
+        del l0
+        with tempfile.TemporaryDirectory(prefix="hipac_tiff_") as d:
+            path = os.path.join(d, "slide.tif")
+            tiff_pyramid.write_tiled_tiff(path, levels, tile=512, compression="jpeg", jpeg_tables=True)
+            px = sum(a.shape[0] * a.shape[1] for a in levels)
+            del levels
+            out = {"side": side, "file_MB": os.path.getsize(path) / 1e6, "tile": 512, "pixels_all_levels": px}
+            for key, flag in (("device_decode_s", True), ("host_decode_s", False)):
+                ts = []
+                for _ in range(2 if flag else 1):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tp = tiff_pyramid.TiffPyramid(path)
+                    lv = tp.to_device_levels(dev, list(range(min(4, tp.level_count))), workers=host_threads(), device_jpeg=flag)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                    del lv
+                out[key] = min(ts)
+            out["device_Gpx_per_s"] = px / out["device_decode_s"] / 1e9
+            out["host_Gpx_per_s"] = px / out["host_decode_s"] / 1e9
+            out["host_threads"] = host_threads()
+        torch.cuda.empty_cache()
+        return out
+    except (RuntimeError, capi.HipacError, OSError) as e:
+        torch.cuda.empty_cache()
+        return {"error": str(e)[:300]}
 
 
 def pcie_inclusive(net, u8_dev, steps):
@@ -586,6 +627,7 @@ def build_parser():
     ap.add_argument("--train_precision", choices=["fp32", "fp16"], default="fp32",
                     help="simclr workload: fp32 (the reference's loop) or fp16 mixed precision (autocast-style)")
     ap.add_argument("--simclr_timeout", type=float, default=240.0, help="N > 1: seconds the bounded `simclr` object may take")
+    ap.add_argument("--no_tiff", action="store_true", help="default workload: skip the `wsi.tiff_ingest` object")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--one_device", action="store_true",
