@@ -15,7 +15,7 @@ def short(name: str) -> str:
     return name[:150]
 
 
-for kt in ("kt_bench", "kt_wsi", "kt_simclr", "kt_simclr_amp"):
+for kt in ("kt_bench", "kt_wsi", "kt_simclr", "kt_simclr_amp", "kt_tiff"):
     for f in glob.glob(os.path.join(out, kt, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         dst = os.path.join(out, kt.replace("kt_", "") + "_kernel_stats.csv")
