@@ -383,7 +383,7 @@ def bench_input_pipeline(n_pairs: int = 256, P: int = 224, steps: int = 5, host_
 
     from PIL import Image
 
-    from . import synth, transforms
+    from . import transforms
 
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(5)

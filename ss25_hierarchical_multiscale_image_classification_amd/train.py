@@ -11,7 +11,6 @@ from typing import Optional
 
 import numpy as np
 import torch
-import torch.nn as nn
 from torch.utils.data import DataLoader, Subset
 
 from .patch_dataset import PatchDataset

@@ -20,7 +20,6 @@ run under ``torch.cuda.amp.autocast()`` (src/main.py:499-508); the classifier tr
 from __future__ import annotations
 
 import ctypes as C
-import math
 import time
 from typing import Dict, List, Optional, Tuple
 
