@@ -68,3 +68,45 @@ def test_missing_tiles_and_the_slide_object(tmp_path):
     slide = extract.DeviceSlide.from_tiff(path, n_levels=3)
     for lv, ref in zip(slide.levels, host):
         assert torch.equal(lv.cpu(), ref)
+
+
+def test_corrupt_entropy_data_is_contained(tmp_path):
+    """Bit flips and truncation inside the entropy-coded segments: every lane's walk still ends (zeros are fed behind a short
+    or broken stream, as libjpeg does), nothing is written outside the tile's own scratch, and the tiles that were not touched
+    decode exactly as before."""
+    levels = _pyramid(1300, 1100, 17)
+    clean = str(tmp_path / "clean.tif")
+    tiff_pyramid.write_tiled_tiff(clean, levels, tile=256, compression="jpeg", quality=85, jpeg_tables=True)
+    ref = [t.cpu() for t, _ in tiff_pyramid.TiffPyramid(clean).to_device_levels("cuda", device_jpeg=False)]
+    data = bytearray(open(clean, "rb").read())
+    tp = tiff_pyramid.TiffPyramid(clean)
+    rng = np.random.default_rng(5)
+    lv0 = tp.levels[0]
+    n = lv0.tiles_across * lv0.tiles_down
+    hit = sorted(rng.choice(n, 6, replace=False).tolist())
+    for k, i in enumerate(hit):
+        off, cnt = lv0.offsets[i], lv0.counts[i]
+        if k % 3 == 0:  # random bit flips behind the (short) tile header
+            for _ in range(40):
+                p = off + 60 + int(rng.integers(0, cnt - 62))
+                data[p] ^= 1 << int(rng.integers(0, 8))
+        elif k % 3 == 1:  # runs of 0xFF (markers / stuffing in the middle of the data)
+            p = off + 80 + int(rng.integers(0, cnt // 2))
+            data[p:p + 9] = b"\xff\x00\xff\xff\xd3\xff\xd9\xff\x17"
+        else:  # the second half of the stream zeroed (a truncated write)
+            data[off + cnt // 2:off + cnt] = bytes(cnt - cnt // 2)
+    broken = str(tmp_path / "broken.tif")
+    open(broken, "wb").write(bytes(data))
+    tpb = tiff_pyramid.TiffPyramid(broken)
+    got = [t.cpu() for t, _ in tpb.to_device_levels("cuda")]
+    assert tpb.device_decoded == sum(l.tiles_across * l.tiles_down for l in tpb.levels)
+    for li, (a, b) in enumerate(zip(got, ref)):
+        if li > 0:
+            assert torch.equal(a, b)
+            continue
+        same = torch.ones(n, dtype=torch.bool)
+        for i in range(n):
+            ty, tx = divmod(i, lv0.tiles_across)
+            ya, xa = ty * 256, tx * 256
+            same[i] = torch.equal(a[ya:ya + 256, xa:xa + 256], b[ya:ya + 256, xa:xa + 256])
+        assert all(bool(same[i]) for i in range(n) if i not in hit)  # the damage stays inside the damaged tiles
