@@ -343,7 +343,7 @@ int hipac_grads_unscale_check(float* grads, int64_t n, float inv_scale, int32_t*
  * openslide.OpenSlide(path) / read_region do with libjpeg on the host for the reference (src/main.py:650, :693).
  * Huffman decoding runs one lane per TILE, then libjpeg's integer ("ISLOW") IDCT, its h2v2 "fancy" chroma upsampling and
  * its fixed-point YCbCr -> RGB: bit-exact against libjpeg / Pillow.  Supported per tile: baseline sequential, 8 bit, 3
- * components in one interleaved scan, 4:2:0 or 4:4:4, Huffman table ids 0 / 1, JPEG size == tile size, tile sides multiples
+ * components in one interleaved scan, 4:2:0, 4:2:2 or 4:4:4, Huffman table ids 0 / 1, JPEG size == tile size, tile sides multiples
  * of 16; every other tile is left untouched and reported in `status_host` so the caller decodes it on the host.
  *   file_host / file_dev : the file's bytes in HOST memory (headers are parsed there) and the same bytes in DEVICE memory
  *                          (16 readable bytes behind the end)

@@ -10,11 +10,11 @@
 //     slow path by maxcode, DC prediction, restart markers) and writes de-zigzagged int16 coefficients;
 //   * jpeg_idct_kernel: one lane per 8x8 block: dequantise + libjpeg's jidctint.c (the "ISLOW" integer IDCT, libjpeg's and
 //     Pillow's default), range limit -> uint8 sample planes;
-//   * jpeg_store_kernel: one lane per pixel: h2v2 "fancy" (triangle) chroma upsampling of jdsample.c with its alternating
+//   * jpeg_store_kernel: one lane per pixel: h2v2 / h2v1 "fancy" (triangle) chroma upsampling of jdsample.c with its alternating
 //     rounding and edge replication, YCbCr -> RGB with jdcolor.c's fixed-point tables, straight into the level image in HBM.
 // Everything is integer arithmetic restated from libjpeg and checked against Pillow's decoder bit for bit
 // (tests/test_gpu_jpeg.py; the formulas were first pinned by a pure-Python restatement on the CPU).  Supported: baseline
-// sequential, 8 bit, three components, 4:2:0 or 4:4:4, Huffman table ids 0 / 1, tile sides that are multiples of 16;
+// sequential, 8 bit, three components, 4:2:0, 4:2:2 or 4:4:4, Huffman table ids 0 / 1, tile sides that are multiples of 16;
 // anything else is reported per tile (status 1) and the caller decodes that tile on the host as before.  Bound: the Huffman
 // kernel's serial bit walk per lane (~2 us per symbol in SIMT -- 64-bit buffer arithmetic on a 32-bit ALU, an LDS look-up and
 // a handful of two-sided branches per symbol; 95 % of a load, its coefficient stores are 5 % of it): latency, not HBM.
@@ -292,6 +292,13 @@ __device__ __forceinline__ int fancy_h2v2(const unsigned char* __restrict__ pl, 
   const int xl = cx > 0 ? cx - 1 : cx;
   return (cs * 3 + (near[xl] * 3 + far[xl]) + 8) >> 4;
 }
+// jdsample.c h2v1_fancy_upsample (4:2:2): 3/4 nearer + 1/4 further column, rounding 1 / 2 alternating, the outermost columns copied
+__device__ __forceinline__ int fancy_h2v1(const unsigned char* __restrict__ pl, int cw, int x, int y) {
+  const unsigned char* row = pl + (size_t)y * cw;
+  const int cx = x >> 1, v = row[cx];
+  if (x & 1) return cx + 1 < cw ? (v * 3 + row[cx + 1] + 2) >> 2 : v;
+  return cx > 0 ? (v * 3 + row[cx - 1] + 1) >> 2 : v;
+}
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
 __global__ __launch_bounds__(256) void jpeg_store_kernel(const unsigned char* __restrict__ planes, long long plane_stride,
@@ -310,10 +317,14 @@ __global__ __launch_bounds__(256) void jpeg_store_kernel(const unsigned char* __
   const int yw = c.bw[0] * 8;
   const int Y = base[c.plane_off[0] + (size_t)y * yw + x];
   int cb, cr;
-  if (c.hs[0] == 2) {
+  if (c.hs[0] == 2 && c.vs[0] == 2) {
     const int cw = c.bw[1] * 8, ch = c.bh[1] * 8;
     cb = fancy_h2v2(base + c.plane_off[1], cw, ch, x, y);
     cr = fancy_h2v2(base + c.plane_off[2], cw, ch, x, y);
+  } else if (c.hs[0] == 2) {
+    const int cw = c.bw[1] * 8;
+    cb = fancy_h2v1(base + c.plane_off[1], cw, x, y);
+    cr = fancy_h2v1(base + c.plane_off[2], cw, x, y);
   } else {
     cb = base[c.plane_off[1] + (size_t)y * yw + x];
     cr = base[c.plane_off[2] + (size_t)y * yw + x];
@@ -550,7 +561,8 @@ int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, i
     }
     const bool s420 = F.hs[0] == 2 && F.vs[0] == 2 && F.hs[1] == 1 && F.vs[1] == 1 && F.hs[2] == 1 && F.vs[2] == 1;
     const bool s444 = F.hs[0] == 1 && F.vs[0] == 1 && F.hs[1] == 1 && F.vs[1] == 1 && F.hs[2] == 1 && F.vs[2] == 1;
-    if (!s420 && !s444) continue;
+    const bool s422 = F.hs[0] == 2 && F.vs[0] == 1 && F.hs[1] == 1 && F.vs[1] == 1 && F.hs[2] == 1 && F.vs[2] == 1;
+    if (!s420 && !s444 && !s422) continue;
     bool ok = true;
     JpegCfg c;
     std::memset(&c, 0, sizeof(c));

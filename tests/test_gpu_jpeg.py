@@ -28,7 +28,7 @@ def _both(path, workers=4):
 @pytest.mark.parametrize("tile,quality,tables,sub,bigtiff,noise", [
     (256, 90, False, -1, False, False), (512, 75, True, -1, True, False), (256, 30, True, -1, False, False),
     (256, 100, False, -1, False, True), (128, 95, True, 0, False, False), (256, 100, False, 0, False, True),
-    (64, 85, False, -1, False, False), (48, 85, False, -1, False, False)])
+    (64, 85, False, -1, False, False), (48, 85, False, -1, False, False), (256, 80, True, 1, False, False), (128, 100, False, 1, True, True)])
 def test_device_jpeg_equals_the_host_decoder(tmp_path, tile, quality, tables, sub, bigtiff, noise):
     levels = _pyramid(1500, 1100, 3 + tile + quality, noise)
     path = str(tmp_path / "s.tif")
@@ -44,7 +44,7 @@ def test_device_jpeg_equals_the_host_decoder(tmp_path, tile, quality, tables, su
 def test_restart_markers_optimised_tables_and_fallbacks(tmp_path):
     levels = _pyramid(900, 700, 8)
     cases = [({"restart_marker_rows": 1}, -1, True), ({"restart_marker_blocks": 5}, 0, True), ({"optimize": True}, -1, True),
-             ({"progressive": True}, -1, False), ({}, 1, False)]  # progressive and 4:2:2 tiles: the host decodes them
+             ({"progressive": True}, -1, False)]  # progressive tiles: the host decodes them
     for k, (opts, sub, on_device) in enumerate(cases):
         path = str(tmp_path / f"s{k}.tif")
         tiff_pyramid.write_tiled_tiff(path, levels, tile=256, compression="jpeg", quality=88, subsampling=sub, jpeg_options=opts)
