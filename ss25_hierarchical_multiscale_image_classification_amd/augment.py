@@ -258,10 +258,10 @@ class DevicePatchPool:
         slot = self._pin_next = (getattr(self, "_pin_next", -1) + 1) % 4
         ring = self.__dict__.setdefault("_pin", [None] * 4)
         evs = self.__dict__.setdefault("_pin_ev", [None] * 4)
+        if evs[slot] is not None:
+            evs[slot].synchronize()  # the copy that last read this slot has run (before the slot is rewritten or replaced)
         if ring[slot] is None or ring[slot].shape[0] < n:
             ring[slot] = torch.empty((n, PARAMS), dtype=torch.int32).pin_memory()
-        if evs[slot] is not None:
-            evs[slot].synchronize()
         host = ring[slot][:n]
         host.numpy()[:] = params
         out = torch.empty((n, 3, OUT, OUT), dtype=torch.float32, device=self.device) if want_float else None
