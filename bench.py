@@ -448,6 +448,8 @@ def run_resnet(args, rank, world, dev):
             out = train_native.bench_simclr_step(sargs, rank, world, dev)  # the reference's arithmetic for this loop
             sargs.train_precision = "fp16"  # mixed precision (the reference's autocast arithmetic of the fine-tune loops)
             out["mixed_precision"] = train_native.bench_simclr_step(sargs, rank, world, dev)
+            if world == 1:  # a-13: the classifier loops' fine-tune step at the reference's batch size, its autocast arithmetic
+                out["classifier_step"] = train_native.bench_classifier_step(512, 3, 1, dev, "fp16")
             if world == 1:  # where the step's input comes from: views made on the device vs the host's Pillow transforms
                 from ss25_hierarchical_multiscale_image_classification_amd import augment
                 out["input_pipeline"] = augment.bench_input_pipeline(n_pairs=256, P=224, steps=5, device=dev)

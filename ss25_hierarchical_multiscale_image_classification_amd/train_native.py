@@ -526,3 +526,30 @@ def bench_simclr_step(args, rank: int, world: int, dev) -> dict:
         if prec == "fp16":
             rec["loss_scale"], rec["skipped_steps"] = trainer.scaler.get_scale(), trainer.scaler.skipped
     return rec
+
+
+def bench_classifier_step(batch: int, steps: int, warmup: int, dev, precision: str = "fp16") -> dict:
+    """The fine-tune step of the classifier loops (SURVEY a-13, src/main.py:494-510 / :575-590): train-mode ResNet18 + fc,
+    weighted cross-entropy, backward, GradScaler, Adam -- on ``batch`` images (the reference's BATCH_SIZE is 512), single GPU."""
+    from .resnet import ResNet18Classifier
+
+    torch.manual_seed(0)
+    trainer = NativeClassifierTrainer(ResNet18Classifier().state_dict(), device=dev, lr=1e-4, class_weights=torch.tensor([1.0, 3.5]),
+                                      precision=precision)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((batch, 3, 224, 224), generator=g, device=dev)
+    y = torch.randint(0, 2, (batch,), generator=torch.Generator().manual_seed(7))
+    for _ in range(warmup):
+        trainer.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = trainer.step(x, y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    imgs = batch * steps
+    tf = 3.0 * FWD_FLOP_PER_IMAGE * imgs / dt / 1e12
+    return {"metric": "classifier fine-tune step, images/s (ResNet18 fwd+bwd, weighted CE, Adam)", "value": imgs / dt, "unit": "images/s",
+            "batch": batch, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "dtype": "f16 (fp32 accumulate, fp32 master weights, GradScaler)" if precision == "fp16" else "f32", "data": "synthetic",
+            "final_loss": float(loss), "tflops": tf, "frac_of_mfma_peak_whole_step": tf / (2500.0 if precision == "fp16" else 157.3)}
