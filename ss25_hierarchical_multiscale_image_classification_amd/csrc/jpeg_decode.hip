@@ -16,10 +16,11 @@
 // (tests/test_gpu_jpeg.py; the formulas were first pinned by a pure-Python restatement on the CPU).  Supported: baseline
 // sequential, 8 bit, three components, 4:2:0, 4:2:2 or 4:4:4, Huffman table ids 0 / 1, tile sides that are multiples of 16;
 // anything else is reported per tile (status 1) and the caller decodes that tile on the host as before.  Bound: the Huffman
-// kernel's serial bit walk per lane (~2 us per symbol in SIMT -- 64-bit buffer arithmetic on a 32-bit ALU, an LDS look-up and
-// a handful of two-sided branches per symbol; 95 % of a load, its coefficient stores are 5 % of it): latency, not HBM.
+// kernel's serial bit walk (~0.6 us per symbol at one stream per wave: a chain of ~150 dependent instructions with an LDS
+// look-up in it; 80 % of a load, its coefficient stores are 5 % of that): latency, not HBM.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -70,12 +71,15 @@ __constant__ unsigned char d_zigzag[64];
 // tile uses another configuration reads its own from global memory), and so does the zigzag order.
 __device__ __forceinline__ int huff_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
+// `lanes` tiles per wave: with few tiles (a slide has thousands, the chip holds 16 384 waves at 16 per SIMD) a wave walks FEWER
+// streams -- its lanes then rarely sit on different sides of a branch, and the SIMDs that would idle hold the other waves,
+// whose latencies overlap.  64 only when there are more tiles than the chip has wave slots.
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* __restrict__ file, const TileDesc* __restrict__ tiles,
                                                          const JpegCfg* __restrict__ cfgs, int n_tiles, short* __restrict__ coef,
-                                                         long long coef_stride) {
+                                                         long long coef_stride, int lanes) {
   __shared__ DevHuff sh[4];  // dc[0], dc[1], ac[0], ac[1] of the first tile's configuration
   __shared__ unsigned char zz[64];
-  const int t0 = blockIdx.x * 64;
+  const int t0 = blockIdx.x * lanes;
   const int cfg0 = tiles[t0].cfg;
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(&cfgs[cfg0].dc[0]);  // dc[2] and ac[2] are contiguous
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   }
   __syncthreads();
   const int t = t0 + threadIdx.x;
-  if (t >= n_tiles) return;
+  if ((int)threadIdx.x >= lanes || t >= n_tiles) return;
   const TileDesc td = tiles[t];
   const JpegCfg& c = cfgs[td.cfg];
   const bool shared_tables = td.cfg == cfg0;
@@ -94,6 +98,9 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   const unsigned char* const end = file + td.end;
   unsigned long long buf = 0;
   int n = 0;
+  const unsigned char* pw = p;  // where the prefetched dword `wq` was read: the stream is fetched one refill ahead
+  unsigned wq;
+  __builtin_memcpy(&wq, p, 4);
   int pred0 = 0, pred1 = 0, pred2 = 0;
   const int dri = c.dri, mcus_x = c.mcus_x, n_mcus = c.mcus_x * c.mcus_y, mcu_blocks = c.mcu_blocks;
   // everything the walk needs from the configuration lives in registers: a load from it would sit in the dependent chain
@@ -120,13 +127,18 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
     if (n < 32) {
       bool fast = false;
       if (p + 4 <= end) {
-        unsigned w;
-        __builtin_memcpy(&w, p, 4);  // unaligned dword
+        if (pw != p) {  // (after the byte-wise path) the dword in hand is not the one at p
+          __builtin_memcpy(&wq, p, 4);
+          pw = p;
+        }
+        const unsigned w = wq;
         const unsigned x = ~w;  // a byte of w is 0xFF  <=>  that byte of x is 0
         if (!((x - 0x01010101u) & ~x & 0x80808080u)) {
           buf = (buf << 32) | (unsigned long long)__builtin_bswap32(w);
           n += 32;
           p += 4;
+          pw = p;
+          __builtin_memcpy(&wq, p, 4);  // requested now, needed ~5 symbols later (the file image has slack behind its end)
           fast = true;
         }
       }
@@ -641,8 +653,11 @@ int hipac_jpeg_decode_tiles(const uint8_t* file_host, const uint8_t* file_dev, i
   HIPAC_CHECK_HIP(hipMemcpyAsync(d_lvl, ldesc.data(), ldesc.size() * sizeof(LevelDesc), hipMemcpyHostToDevice, s));
   HIPAC_CHECK_HIP(hipMemcpyAsync(d_desc, descs.data(), (size_t)nd * sizeof(TileDesc), hipMemcpyHostToDevice, s));
   HIPAC_CHECK_HIP(hipMemsetAsync(d_coef, 0, (size_t)nd * coef_stride * 2, s));
-  hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)((nd + 63) / 64)), dim3(64), 0, s, (const unsigned char*)file_dev,
-                     (const TileDesc*)d_desc, (const JpegCfg*)d_cfg, nd, d_coef, coef_stride);
+  int lanes = (nd + 16383) / 16384;  // tiles per wave: 16 waves on every SIMD before a wave takes a second stream
+  lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+  if (const char* e = getenv("HIPAC_JPEG_LANES")) lanes = atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : lanes;  // developer knob
+  hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)((nd + lanes - 1) / lanes)), dim3(64), 0, s, (const unsigned char*)file_dev,
+                     (const TileDesc*)d_desc, (const JpegCfg*)d_cfg, nd, d_coef, coef_stride, lanes);
   const long long nblk = (long long)nd * max_blocks;
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, (const short*)d_coef, coef_stride,
                      (const TileDesc*)d_desc, (const JpegCfg*)d_cfg, nd, max_blocks, d_planes, plane_stride);
