@@ -429,7 +429,7 @@ def run_resnet(args, rank, world, dev):
                 w["parity_mode"] = {"error": str(e)[:300]}
             torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not args.no_tiff:
-            w["tiff_ingest"] = tiff_ingest_object(dev)
+            w["tiff_ingest"] = tiff_ingest_object(dev, net)
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
                 w["cpu_baseline"] = cpu_baseline_wsi()
@@ -475,7 +475,7 @@ def run_resnet(args, rank, world, dev):
     return rec
 
 
-def tiff_ingest_object(dev, side=20000):
+def tiff_ingest_object(dev, net=None, side=20000):
     """How a slide FILE gets into HBM: a synthetic `side`^2 pyramid written as a tiled TIFF with JPEG tiles (512 x 512, 4:2:0, one
     JPEGTables set per level -- the CAMELYON16 layout), loaded with the tiles decoded on the device (hipac_jpeg_decode_tiles) and,
     for comparison, on the host's threads (Pillow / libjpeg-turbo).  Both give the same bytes (tests/test_gpu_jpeg.py)."""
@@ -504,6 +504,14 @@ def tiff_ingest_object(dev, side=20000):
                     ts.append(time.perf_counter() - t0)
                     del lv
                 out[key] = min(ts)
+            if net is not None:  # the whole way: file on disk -> levels in HBM -> every window of levels 0-3 scored (a first scan)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                slide = extract.DeviceSlide.from_tiff(path, device=dev, workers=host_threads())
+                f, _, _, _ = extract.score_slide(slide, net, levels=(0, 1, 2, 3))
+                torch.cuda.synchronize()
+                out["file_to_scores_s"], out["kept_windows"] = time.perf_counter() - t0, int(f.shape[0])
+                del slide, f
             out["device_Gpx_per_s"] = px / out["device_decode_s"] / 1e9
             out["host_Gpx_per_s"] = px / out["host_decode_s"] / 1e9
             out["host_threads"] = host_threads()
