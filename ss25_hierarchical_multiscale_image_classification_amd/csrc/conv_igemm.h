@@ -313,7 +313,7 @@ __device__ __forceinline__ void split_pair4(const float* v, f16x4& hi, f16x4& lo
 }
 
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BM, int BN, int NSTAGE,
-          bool RELU, bool RESID, bool OUTF32, bool PROJ = false, bool SPLIT = false, int WTM = 64>
+          bool RELU, bool RESID, bool OUTF32, bool PROJ = false, bool SPLIT = false, int WTM = 64, int TKH = 0, int TKW = 0, int UPS = 0>
 __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kernel(
     const T* __restrict__ in, const T* __restrict__ wgt, const float* __restrict__ bias,
     const T* __restrict__ resid, void* __restrict__ outp, int M, int n_mtiles, const char* __restrict__ zero_page,
@@ -321,14 +321,20 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kern
     void* __restrict__ outp_p = nullptr) {
   using E = Elem<T>;
   using frag = typename E::frag;
-  constexpr int PAD = KS / 2;
-  constexpr int HO = (HI + 2 * PAD - KS) / STRIDE + 1;
-  constexpr int WO = (WI + 2 * PAD - KS) / STRIDE + 1;
+  // UPS != 0 (training: data gradient of a stride-2 conv, one PARITY CLASS of the fine grid per launch): the input is the
+  // gradient on the coarse grid, the window is TKH x TKW taps starting AT the output pixel (no padding; taps beyond the
+  // bottom / right edge read zeros), the output grid equals the input grid and output pixel (y, x) is stored at fine
+  // position (2y + PY, 2x + PX), UPS = 4 | PY << 1 | PX.  See launch_dgrad_s2.
+  constexpr int KH = UPS ? TKH : KS, KW = UPS ? TKW : KS;
+  constexpr int PAD = UPS ? 0 : KS / 2;
+  constexpr int HO = UPS ? HI : (HI + 2 * PAD - KS) / STRIDE + 1;
+  constexpr int WO = UPS ? WI : (WI + 2 * PAD - KS) / STRIDE + 1;
+  static_assert(!UPS || (STRIDE == 1 && TKH >= 1 && TKW >= 1 && !PROJ && !RESID && !OUTF32 && !SPLIT), "parity-class data gradient");
   constexpr int RC = CIN / 64;                      // real 64-channel chunks
   constexpr int CC = SPLIT ? 3 * RC : RC;           // (virtual) chunks of the K loop
   constexpr int PIXC = SPLIT ? 2 * CIN : CIN;       // activation elements per input pixel
   constexpr int OPIX = SPLIT ? 2 * COUT : COUT;     // elements per output pixel (T outputs)
-  constexpr int KT = KS * KS * CC;
+  constexpr int KT = KH * KW * CC;
   constexpr int KTOT = KT * 64;
   constexpr int KTP = PROJ ? KT + CC : KT;          // + the projection's K tiles
   static_assert(!PROJ || (KS == 3 && STRIDE == 2 && !RESID && !OUTF32), "projection rides on 3x3/2 only");
@@ -366,7 +372,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kern
   const int prow = lane >> 3;     // row inside the 8-row piece
   const int dchunk = lane & 7;    // destination 16-byte chunk (lane-linear)
   int a_off[APW];                 // byte offset of tap (0,0), incl. the swizzled source chunk
-  unsigned a_mask[APW];           // bit (kh*KS+kw): tap inside the image
+  unsigned a_mask[APW];           // bit (kh*KW+kw): tap inside the image
 #pragma unroll
   for (int i = 0; i < APW; ++i) {
     const int row = (wave + NWAVES * i) * 8 + prow;  // row inside the BM tile
@@ -381,11 +387,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kern
     a_off[i] = (((b * HI + ih0) * WI + iw0) * PIXC + schunk * 8) * 2;
     unsigned mask = 0;
 #pragma unroll
-    for (int kh = 0; kh < KS; ++kh)
+    for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < KS; ++kw)
+      for (int kw = 0; kw < KW; ++kw)
         if (ok && (unsigned)(ih0 + kh) < (unsigned)HI && (unsigned)(iw0 + kw) < (unsigned)WI)
-          mask |= 1u << (kh * KS + kw);
+          mask |= 1u << (kh * KW + kw);
     a_mask[i] = mask;
   }
   int w_off[WPW], wp_off[PROJ ? WPW : 1];
@@ -448,11 +454,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kern
       const int pc = i_t - KT;
       issue(4, ((WI + 1) * PIXC + split_achunk<SPLIT, RC>(pc) * 64) * 2, pc * 128, i_t % NSTAGE, true);
     } else {
-      const int tap = i_kh * KS + i_kw;
+      const int tap = i_kh * KW + i_kw;
       issue(tap, ((i_kh * WI + i_kw) * PIXC + split_achunk<SPLIT, RC>(i_cc) * 64) * 2, i_t * 128, i_t % NSTAGE, false);
       if (++i_cc == CC) {
         i_cc = 0;
-        if (++i_kw == KS) {
+        if (++i_kw == KW) {
           i_kw = 0;
           ++i_kh;
         }
@@ -562,7 +568,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 2) void conv_glds_kern
         float v1 = acc[i][j][4 * q + 1] + bv.y;
         float v2 = acc[i][j][4 * q + 2] + bv.z;
         float v3 = acc[i][j][4 * q + 3] + bv.w;
-        const size_t o = (size_t)m * COUT + c0;
+        size_t o = (size_t)m * COUT + c0;
+        if constexpr (UPS != 0) {  // coarse pixel m = (b, y, x) -> fine position (2y + PY, 2x + PX)
+          const int ub = m / (HO * WO), urem = m - ub * (HO * WO), uy = urem / WO, ux = urem - uy * WO;
+          o = ((size_t)(ub * 2 * HO + 2 * uy + ((UPS >> 1) & 1)) * (2 * WO) + 2 * ux + (UPS & 1)) * COUT + c0;
+        }
         if constexpr (RESID) {
           const typename E::vec4 rv = *reinterpret_cast<const typename E::vec4*>(resid + o);
           v0 += (float)rv[0];
@@ -2723,6 +2733,42 @@ static int launch_conv_projk(const void* tmp, const ConvW& w2, const ConvW& wp, 
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)tmp, (const T*)w2.w, bias_sum, (const T*)xblk, out, M, n, n_mtiles,
                      zero_page, (const T*)wp.w);
   return (int)hipGetLastError();
+}
+
+// Data gradient of a stride-2 convolution (training) WITHOUT the zero-interleaved gradient map: the fine grid falls into four
+// parity classes; input position (2y + PY, 2x + PX) only ever meets the taps kh with kh + PY odd ... i.e. kh = 1 for PY = 0 and
+// kh in {0, 2} for PY = 1 (same in x): 1, 2, 2 and 4 taps instead of 9 each -- a quarter of the MFMAs of the 3x3 convolution
+// over the zero-interleaved map.  `g` = gradient wrt the conv output on the coarse HC x HC grid [n][HC][HC][CG]; `wc` = the class's
+// weights [CX][taps][CG] (pack mode 3 of train_amp.hip); `dx` = [n][2 HC][2 HC][CX], this class's positions written.
+template <typename T, int CG, int CX, int HC, int TKH, int TKW, int PY, int PX>
+static int launch_dgrad_s2_class(const void* g, const void* wc, const float* zero_bias, void* dx, int n, hipStream_t s,
+                                 const char* zero_page) {
+  using C = TileCfg<CX>;
+  constexpr int BM = C::BM, BN = C::BN, NSTAGE = C::NSTAGE;
+  constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
+  constexpr int LDS = NSTAGE * (BM + BN) * 128;
+  auto kern = conv_glds_kernel<T, CG, CX, HC, HC, 1, 1, BM, BN, NSTAGE, false, false, false, false, false, 64, TKH, TKW, 4 | (PY << 1) | PX>;
+  static bool attr_done[kMaxDevices] = {};
+  if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+  const int M = n * HC * HC;
+  const int n_mtiles = (M + BM - 1) / BM;
+  const int mt8 = (n_mtiles + 7) / 8 * 8;
+  dim3 grid(mt8 * (CX / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(THREADS), LDS, s, (const T*)g, (const T*)wc, zero_bias, (const T*)nullptr, dx, M, n_mtiles,
+                     zero_page, (const T*)nullptr, (const float*)nullptr, (void*)nullptr);
+  return (int)hipGetLastError();
+}
+// all four classes of a 3x3 / stride 2 conv (KS3 = true) or the one class of a 1x1 / stride 2 conv (the other positions of dx
+// must have been zeroed): wc = the four class blocks back to back (1, 2, 2, 4 taps) or the 1x1 matrix [CX][CG]
+template <typename T, int CG, int CX, int HC, bool KS3>
+static int launch_dgrad_s2(const void* g, const void* wc, const float* zero_bias, void* dx, int n, hipStream_t s, const char* zero_page) {
+  const T* w = (const T*)wc;
+  constexpr size_t blk = (size_t)CX * CG;
+  if constexpr (!KS3) return launch_dgrad_s2_class<T, CG, CX, HC, 1, 1, 0, 0>(g, w, zero_bias, dx, n, s, zero_page);
+  if (int rc = launch_dgrad_s2_class<T, CG, CX, HC, 1, 1, 0, 0>(g, w, zero_bias, dx, n, s, zero_page)) return rc;
+  if (int rc = launch_dgrad_s2_class<T, CG, CX, HC, 1, 2, 0, 1>(g, w + blk, zero_bias, dx, n, s, zero_page)) return rc;
+  if (int rc = launch_dgrad_s2_class<T, CG, CX, HC, 2, 1, 1, 0>(g, w + 3 * blk, zero_bias, dx, n, s, zero_page)) return rc;
+  return launch_dgrad_s2_class<T, CG, CX, HC, 2, 2, 1, 1>(g, w + 5 * blk, zero_bias, dx, n, s, zero_page);
 }
 
 #ifndef HIPAC_USE_S2C64

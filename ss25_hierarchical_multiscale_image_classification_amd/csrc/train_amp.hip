@@ -85,7 +85,8 @@ static AmpPlan make_amp_plan(int B) {
 // ---------------------------------------------------------------------------------------------
 // small kernels (fp16 storage, fp32 / fp64 arithmetic)
 // ---------------------------------------------------------------------------------------------
-// fp32 [co][ci][kh][kw] -> fp16: mode 0 forward [co][(kh,kw)][ci], 1 data gradient [ci][flipped (kh,kw)][co], 2 stem [co][kh*32+kw*4+ci]
+// fp32 [co][ci][kh][kw] -> fp16: mode 0 forward [co][(kh,kw)][ci], 1 data gradient [ci][flipped (kh,kw)][co], 2 stem [co][kh*32+kw*4+ci],
+// 3 data gradient of a 3x3 / stride 2 conv, four parity-class blocks
 __global__ __launch_bounds__(256) void pack_w_h_kernel(const float* __restrict__ w, h16* __restrict__ dst, int cout, int cin,
                                                        int ks, int mode) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -98,7 +99,15 @@ __global__ __launch_bounds__(256) void pack_w_h_kernel(const float* __restrict__
   const h16 v = (h16)w[gid];
   if (mode == 0) dst[(size_t)co * ks * ks * cin + (size_t)(kh * ks + kw) * cin + ci] = v;
   else if (mode == 1) dst[(size_t)ci * ks * ks * cout + (size_t)((ks - 1 - kh) * ks + ks - 1 - kw) * cout + co] = v;
-  else dst[(size_t)co * 224 + kh * 32 + kw * 4 + ci] = v;
+  else if (mode == 3) {
+    // data gradient of a 3x3 / stride 2 conv by parity class (launch_dgrad_s2, conv_igemm.h): class (py, px) = (kh != 1, kw != 1),
+    // its taps (a, b) = ((2 - kh) / 2, (2 - kw) / 2) -- tap a = 0 is the coarse row of the output position itself (kh = 2), a = 1 the
+    // row below (kh = 0); blocks of 1, 2, 2, 4 taps back to back, each [ci][tap][co]
+    const int py = kh != 1, px = kw != 1, a = py ? (2 - kh) / 2 : 0, b = px ? (2 - kw) / 2 : 0;
+    const int ntap = (py ? 2 : 1) * (px ? 2 : 1), tap = a * (px ? 2 : 1) + b;
+    const size_t blk = (size_t)cin * cout, off = (py ? 3 : 0) * blk + (px ? (py ? 2 : 1) : 0) * blk;
+    dst[off + (size_t)ci * ntap * cout + (size_t)tap * cout + co] = v;
+  } else dst[(size_t)co * 224 + kh * 32 + kw * 4 + ci] = v;
 }
 
 __device__ __forceinline__ void ld8(const h16* p, float (&v)[8]) {
@@ -615,6 +624,26 @@ static int conv_forward_h(int i, const h16* in, const h16* wp, const float* zb, 
     default: return conv_h<256, 512, 14, 1, 2>(in, wp, zb, out, n, s, zp);
   }
 }
+#ifndef HIPAC_AMP_DGRAD_CLASSES
+#define HIPAC_AMP_DGRAD_CLASSES 1  // stride-2 data gradients by parity class (1/4 of the MFMAs, no zero-interleaved map); 0: round-3 first form
+#endif
+// data gradient of a STRIDE-2 conv i by parity classes: g = gradient wrt the conv output on the coarse grid, weights in mode 3
+// (3x3) or mode 1 (1x1; `out` zeroed by the caller)
+static int conv_dgrad_s2_h(int i, const h16* g, const h16* wd, const float* zb, h16* out, int n, hipStream_t s, const char* zp) {
+  const ConvDesc& d = kConvs[i];
+  if (d.ks == 3) {
+    switch (d.cout) {
+      case 128: return launch_dgrad_s2<h16, 128, 64, 28, true>(g, wd, zb, out, n, s, zp);
+      case 256: return launch_dgrad_s2<h16, 256, 128, 14, true>(g, wd, zb, out, n, s, zp);
+      default: return launch_dgrad_s2<h16, 512, 256, 7, true>(g, wd, zb, out, n, s, zp);
+    }
+  }
+  switch (d.cout) {
+    case 128: return launch_dgrad_s2<h16, 128, 64, 28, false>(g, wd, zb, out, n, s, zp);
+    case 256: return launch_dgrad_s2<h16, 256, 128, 14, false>(g, wd, zb, out, n, s, zp);
+    default: return launch_dgrad_s2<h16, 512, 256, 7, false>(g, wd, zb, out, n, s, zp);
+  }
+}
 // data gradient of conv i: g = gradient wrt the conv output (stride 2: already zero-interleaved to hin x hin), weights in mode 1
 static int conv_dgrad_h(int i, const h16* g, const h16* wd, const float* zb, h16* out, int n, hipStream_t s, const char* zp) {
   const ConvDesc& d = kConvs[i];
@@ -871,19 +900,33 @@ int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, i
       TRY(conv_dgrad_h(c2, gB, wd, zb, gC, n, s, zp));
       TRY(bn_backward_h(c, c1, n, gC, post(c1), gC, grads, accumulate));
       TRY(conv_wgrad_h(c, c1, n, xin_blk, gC, grads, accumulate));
-      TRY(pack_weights_h(params + param_offset(c1), wd, c1, 1, s));
-      const h16* g1 = gC;
-      if (d1.stride == 2) {
-        const long long nu8 = (long long)n * d1.hin * d1.hin * d1.cout / 8;
-        hipLaunchKernelGGL(upsample_zero_h_kernel, dim3(grid_for(nu8)), dim3(256), 0, s, (const h16*)gC, up, nu8, d1.hout, d1.cout);
-        TRY((int)hipGetLastError());
-        g1 = up;
+      if (d1.stride == 2 && HIPAC_AMP_DGRAD_CLASSES) {
+        TRY(pack_weights_h(params + param_offset(c1), wd, c1, 3, s));
+        TRY(conv_dgrad_s2_h(c1, gC, wd, zb, gB, n, s, zp));
+      } else {
+        TRY(pack_weights_h(params + param_offset(c1), wd, c1, 1, s));
+        const h16* g1 = gC;
+        if (d1.stride == 2) {
+          const long long nu8 = (long long)n * d1.hin * d1.hin * d1.cout / 8;
+          hipLaunchKernelGGL(upsample_zero_h_kernel, dim3(grid_for(nu8)), dim3(256), 0, s, (const h16*)gC, up, nu8, d1.hout, d1.cout);
+          TRY((int)hipGetLastError());
+          g1 = up;
+        }
+        TRY(conv_dgrad_h(c1, g1, wd, zb, gB, n, s, zp));
       }
-      TRY(conv_dgrad_h(c1, g1, wd, zb, gB, n, s, zp));
       if (down) {
         TRY(bn_backward_h(c, ds, n, gA, nullptr, gC, grads, accumulate));
         TRY(conv_wgrad_h(c, ds, n, xin_blk, gC, grads, accumulate));
         TRY(pack_weights_h(params + param_offset(ds), wd, ds, 1, s));
+        if (HIPAC_AMP_DGRAD_CLASSES) {
+          // 1x1 / stride 2: only the even positions of the fine grid receive a gradient; `up` takes it (gC holds the input)
+          HIPAC_CHECK_HIP(hipMemsetAsync(up, 0, (size_t)n * d1.hin * d1.hin * kConvs[ds].cin * 2, s));
+          TRY(conv_dgrad_s2_h(ds, gC, wd, zb, up, n, s, zp));
+          hipLaunchKernelGGL(add_mask_h_kernel, dim3(grid_for(n_in8)), dim3(256), 0, s, (const h16*)gB, (const h16*)up, prev_post, gA,
+                             n_in8);
+          TRY((int)hipGetLastError());
+          continue;
+        }
         const long long nu8 = (long long)n * d1.hin * d1.hin * kConvs[ds].cout / 8;
         hipLaunchKernelGGL(upsample_zero_h_kernel, dim3(grid_for(nu8)), dim3(256), 0, s, (const h16*)gC, up, nu8, kConvs[ds].hout,
                            kConvs[ds].cout);
