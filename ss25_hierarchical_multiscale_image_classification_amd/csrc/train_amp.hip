@@ -156,6 +156,25 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const h16* __restrict_
         }
       }
     }
+    if (MODE == 1) {
+      // two rows (six loads) in flight per thread, added in row order
+      for (; r + step < M; r += 2 * step) {
+        float va[8], vb[8], xa[8], xb[8];
+        ld8(a + r * C + 8 * g, va), ld8(a + (r + step) * C + 8 * g, vb);
+        ld8(x + r * C + 8 * g, xa), ld8(x + (r + step) * C + 8 * g, xb);
+        if (ymask) {
+          float ma[8], mb[8];
+          ld8(ymask + r * C + 8 * g, ma), ld8(ymask + (r + step) * C + 8 * g, mb);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) va[k] = ma[k] > 0.f ? va[k] : 0.f, vb[k] = mb[k] > 0.f ? vb[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s[k] += va[k], q[k] += (double)va[k] * ((xa[k] - mu[k]) * rs[k]);
+          s[k] += vb[k], q[k] += (double)vb[k] * ((xb[k] - mu[k]) * rs[k]);
+        }
+      }
+    }
     for (; r < M; r += step) {
       float v[8];
       ld8(a + r * C + 8 * g, v);
