@@ -9,8 +9,10 @@
 
 namespace hipac {
 
-constexpr int kNtR = 16;   // rows per workgroup
+constexpr int kNtR = 8;    // rows per workgroup (2N = 2048 rows -> 256 workgroups: one per CU)
 constexpr int kNtC = 64;   // columns per tile
+constexpr int kTPR = 256 / kNtR;   // threads per row in the row-wise phases (32: a half wave)
+constexpr int kDPT = 256 / kTPR;   // dims per thread in the backward accumulation (D <= 256)
 
 __global__ __launch_bounds__(256) void ntx_normalize_kernel(const float* __restrict__ z, int rows, int D,
                                                             float* __restrict__ zn, float* __restrict__ inv_norm) {
@@ -58,7 +60,7 @@ __device__ __forceinline__ void ntx_load_tiles(const float* zn, int D, int rows,
 // forward: lse[i], and loss += sum_i (lse_i - S_{i,pair(i)}) / rows
 __global__ __launch_bounds__(256) void ntx_forward_kernel(const float* __restrict__ zn, int rows, int N, int D,
                                                           float inv_t, float* __restrict__ lse,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ terms) {
   extern __shared__ float sm[];
   float* zi = sm;                          // [kNtR][D]
   float* zj = zi + kNtR * D;               // [kNtC][D + 1]
@@ -76,17 +78,17 @@ __global__ __launch_bounds__(256) void ntx_forward_kernel(const float* __restric
     __syncthreads();
     ntx_tile_scores(zi, zj, D, r0, c0, rows, inv_t, st);
     __syncthreads();
-    // one wave-quarter (16 lanes) per row: online logsumexp over the tile's 64 columns
-    const int a = threadIdx.x >> 4, l = threadIdx.x & 15;
+    // kTPR lanes per row: online logsumexp over the tile's 64 columns
+    const int a = threadIdx.x / kTPR, l = threadIdx.x % kTPR;
     float m = -INFINITY;
-    for (int b = l; b < kNtC; b += 16) m = fmaxf(m, st[a * (kNtC + 1) + b]);
-    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+    for (int b = l; b < kNtC; b += kTPR) m = fmaxf(m, st[a * (kNtC + 1) + b]);
+    for (int o = kTPR / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kTPR));
     const float m_old = red[a * 3 + 0];
     const float m_new = fmaxf(m_old, m);
     float s = 0.f;
     if (m_new > -INFINITY)
-      for (int b = l; b < kNtC; b += 16) s += expf(st[a * (kNtC + 1) + b] - m_new);
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+      for (int b = l; b < kNtC; b += kTPR) s += expf(st[a * (kNtC + 1) + b] - m_new);
+    for (int o = kTPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kTPR);
     const int i = r0 + a, pj = i < N ? i + N : i - N;  // pair(i)
     __syncthreads();
     if (l == 0) {
@@ -100,8 +102,21 @@ __global__ __launch_bounds__(256) void ntx_forward_kernel(const float* __restric
     const int a = threadIdx.x;
     const float l = red[a * 3 + 0] + logf(red[a * 3 + 1]);
     lse[r0 + a] = l;
-    atomicAdd(loss, (l - red[a * 3 + 2]) / (float)rows);
+    terms[r0 + a] = l - red[a * 3 + 2];  // summed in row order by ntx_loss_kernel (no atomics: the loss value is reproducible)
   }
+}
+
+__global__ __launch_bounds__(256) void ntx_loss_kernel(const float* __restrict__ terms, int rows, float* __restrict__ loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) s += terms[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)rows;
 }
 
 // backward: dz rows r0 .. r0 + kNtR - 1
@@ -116,11 +131,11 @@ __global__ __launch_bounds__(256) void ntx_backward_kernel(const float* __restri
   float* ls = st + kNtR * (kNtC + 1);      // lse of the tile's columns [kNtC]
   float* lr = ls + kNtC;                   // lse of the workgroup's rows [kNtR]
   const int r0 = blockIdx.x * kNtR;
-  // thread -> (row a, dims d0 + 16 * t): 16 threads per row, D / 16 dims each (D <= 256)
-  const int a = threadIdx.x >> 4, l = threadIdx.x & 15;
-  float g[16];
+  // thread -> (row a, dims l + kTPR * t): kTPR threads per row, D / kTPR dims each (D <= 256)
+  const int a = threadIdx.x / kTPR, l = threadIdx.x % kTPR;
+  float g[kDPT];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) g[t] = 0.f;
+  for (int t = 0; t < kDPT; ++t) g[t] = 0.f;
   const int i = r0 + a;
   if (threadIdx.x < kNtR) lr[threadIdx.x] = r0 + (int)threadIdx.x < rows ? lse[r0 + threadIdx.x] : 0.f;
   for (int c0 = 0; c0 < rows; c0 += kNtC) {
@@ -147,26 +162,26 @@ __global__ __launch_bounds__(256) void ntx_backward_kernel(const float* __restri
       for (int b = 0; b < kNtC; ++b) {
         const float c = st[a * (kNtC + 1) + b];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int d = l + 16 * t;
+        for (int t = 0; t < kDPT; ++t) {
+          const int d = l + kTPR * t;
           if (d < D) g[t] = fmaf(c, zj[b * (D + 1) + d], g[t]);
         }
       }
     }
   }
-  if (i >= rows) return;  // whole 16-lane groups leave together (a = row)
+  if (i >= rows) return;  // whole kTPR-lane groups leave together (a = row)
   // dzn = g * gscale;  dz = (dzn - zn (zn . dzn)) * inv_norm
   float dot = 0.f;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int d = l + 16 * t;
+  for (int t = 0; t < kDPT; ++t) {
+    const int d = l + kTPR * t;
     if (d < D) dot = fmaf(zi[a * D + d], g[t] * gscale, dot);
   }
-  for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+  for (int o = kTPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, kTPR);
   const float inv = inv_norm[i];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int d = l + 16 * t;
+  for (int t = 0; t < kDPT; ++t) {
+    const int d = l + kTPR * t;
     if (d < D) dz[(size_t)i * D + d] = (g[t] * gscale - zi[a * D + d] * dot) * inv;
   }
 }
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void ntx_backward_kernel(const float* __restri
 
 extern "C" size_t hipac_ntxent_scratch_bytes(int n, int d) {
   if (n <= 0 || d <= 0) return 0;
-  return ((size_t)2 * n * d + (size_t)4 * n) * sizeof(float);  // zn [2N][D], inv_norm [2N], lse [2N]
+  return ((size_t)2 * n * d + (size_t)6 * n) * sizeof(float);  // zn [2N][D], inv_norm [2N], lse [2N], per-row loss terms [2N]
 }
 
 extern "C" int hipac_ntxent_fwd_bwd(const float* z, int n, int d, float temperature, float* loss, float* dz,
@@ -191,12 +206,13 @@ extern "C" int hipac_ntxent_fwd_bwd(const float* z, int n, int d, float temperat
   float* zn = (float*)scratch;
   float* inv_norm = zn + (size_t)rows * d;
   float* lse = inv_norm + rows;
-  HIPAC_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+  float* terms = lse + rows;
   hipLaunchKernelGGL(ntx_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, z, rows, d, zn, inv_norm);
   const size_t lds =
       ((size_t)kNtR * d + (size_t)kNtC * (d + 1) + (size_t)kNtR * (kNtC + 1) + kNtC + kNtR) * sizeof(float);
   const int blocks = (rows + kNtR - 1) / kNtR;
-  hipLaunchKernelGGL(ntx_forward_kernel, dim3(blocks), dim3(256), lds, s, zn, rows, n, d, 1.f / temperature, lse, loss);
+  hipLaunchKernelGGL(ntx_forward_kernel, dim3(blocks), dim3(256), lds, s, zn, rows, n, d, 1.f / temperature, lse, terms);
+  hipLaunchKernelGGL(ntx_loss_kernel, dim3(1), dim3(256), 0, s, (const float*)terms, rows, loss);
   if (dz)
     hipLaunchKernelGGL(ntx_backward_kernel, dim3(blocks), dim3(256), lds, s, zn, inv_norm, lse, rows, n, d,
                        1.f / temperature, 1.f / ((float)rows * temperature), dz);
