@@ -386,43 +386,63 @@ __global__ __launch_bounds__(256) void maxpool_idx_h_kernel(const h16* __restric
   *reinterpret_cast<u32x2*>(idx + gid * 8) = u32x2{lo, hi};
 }
 
-// max-pool backward (gather form): every input position sums the gradients of the <= 4 windows that chose it
+// max-pool backward (gather form): every input position sums the gradients of the <= 4 windows that chose it.  A thread owns a
+// 2 x 2 quad of input positions (2y .. 2y+1, 2x .. 2x+1) x 8 channels: the quad only ever belongs to the four windows
+// (y .. y+1) x (x .. x+1) -- row 2y to window row y alone (dy = 1), row 2y+1 to window rows y (dy = 2) and y+1 (dy = 0) -- so four
+// window loads serve four outputs (one thread per position loaded nine for four)
 __global__ __launch_bounds__(256) void maxpool_bwd_h_kernel(const h16* __restrict__ dout, const unsigned char* __restrict__ idx,
                                                             h16* __restrict__ din, long long total8) {
   constexpr int HI = 112, HO = 56, C = 64;
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, y, x, c8) over the 56 x 56 quads
   if (gid >= total8) return;
   const int c8 = (int)(gid % (C / 8));
   long long p = gid / (C / 8);
-  const int iw = (int)(p % HI);
-  p /= HI;
-  const int ih = (int)(p % HI);
-  const long long b = p / HI;
-  float acc[8];
+  const int x = (int)(p % HO);
+  p /= HO;
+  const int y = (int)(p % HO);
+  const long long b = p / HO;
+  float acc[2][2][8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int t = ih + 1 - dy;
-    if (t < 0 || (t & 1)) continue;
-    const int oh = t >> 1;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[i][j][k] = 0.f;
+#pragma unroll
+  for (int wy = 0; wy < 2; ++wy) {
+    const int oh = y + wy;
     if (oh >= HO) continue;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int u = iw + 1 - dx;
-      if (u < 0 || (u & 1)) continue;
-      const int ow = u >> 1;
+    for (int wx = 0; wx < 2; ++wx) {
+      const int ow = x + wx;
       if (ow >= HO) continue;
       const long long o = ((b * HO + oh) * HO + ow) * C + 8 * c8;
       const u32x2 ib = *reinterpret_cast<const u32x2*>(idx + o);
       float g[8];
       ld8(dout + o, g);
+      // window (oh, ow) covers input rows 2 oh - 1 + dy: quad row i = 0 (input row 2y) is dy = 1 of wy = 0; quad row i = 1
+      // (input row 2y + 1) is dy = 2 of wy = 0 and dy = 0 of wy = 1 -- the same in x
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if ((int)(((k < 4 ? ib[0] : ib[1]) >> (8 * (k & 3))) & 0xffu) == dy * 3 + dx) acc[k] += g[k];
+      for (int i = 0; i < 2; ++i) {
+        const int dy = wy == 0 ? 1 + i : (i == 1 ? 0 : -1);
+        if (dy < 0) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int dx = wx == 0 ? 1 + j : (j == 1 ? 0 : -1);
+          if (dx < 0) continue;
+          const int code = dy * 3 + dx;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if ((int)(((k < 4 ? ib[0] : ib[1]) >> (8 * (k & 3))) & 0xffu) == code) acc[i][j][k] += g[k];
+        }
+      }
     }
   }
-  st8(din + gid * 8, acc);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      st8(din + (((b * HI + 2 * y + i) * HI + 2 * x + j) * C + 8 * c8), acc[i][j]);
 }
 
 __global__ __launch_bounds__(256) void avgpool_h_kernel(const h16* __restrict__ last, float* __restrict__ feats, int n) {
@@ -976,7 +996,7 @@ int hipac_train_amp_encoder_backward(const float* params, const float* dfeats, i
     }
   }
   {
-    const long long total = (long long)n * 112 * 112 * 8;  // 8 channels per thread
+    const long long total = (long long)n * 56 * 56 * 8;  // a 2 x 2 quad of positions x 8 channels per thread
     hipLaunchKernelGGL(maxpool_bwd_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16*)gA,
                        (const unsigned char*)(ws + p.pool_idx), gB, total);
     TRY((int)hipGetLastError());
