@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define HIPAC_ABI_VERSION 6  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3; 4: hipac_train_amp_*; 5: hipac_augment_views; 6: hipac_jpeg_decode_tiles */
+#define HIPAC_ABI_VERSION 7  /* 2: the native training entry points (round 2); 3: HIPAC_PREC_FP16X3; 4: hipac_train_amp_*; 5: hipac_augment_views; 6: hipac_jpeg_decode_tiles; 7: larger scratch of hipac_cross_entropy_fwd_bwd, workspaces of the fp32 training step */
 
 /* error codes (positive small values are hipError_t) */
 #define HIPAC_EINVAL (-1)     /* bad argument (shape, enum, null pointer, alignment) */
@@ -407,7 +407,8 @@ int hipac_linear_backward(const float* x, const float* w, const float* dy, const
                           float* dw, float* db, int M, int N, int K, int accumulate, void* stream);
 
 /* nn.CrossEntropyLoss(weight = class_w) value and gradient (src/main.py:490, :552-566): logits [M][C],
- * labels int64 [M], class_w [C] or NULL, loss float[1], dlogits [M][C], scratch float[2]; all device.
+ * labels int64 [M], class_w [C] or NULL, loss float[1], dlogits [M][C], scratch float[2 + 8 * ceil(M / 256)]
+ * (per-wave partial sums, added in a fixed order: the loss is reproducible); all device.
  * A label outside [0, C) (torch raises there) is never dereferenced: the loss and that row's gradient come out NaN. */
 int hipac_cross_entropy_fwd_bwd(const float* logits, const int64_t* labels, const float* class_w, int M, int C,
                                 float* loss, float* dlogits, float* scratch, void* stream);

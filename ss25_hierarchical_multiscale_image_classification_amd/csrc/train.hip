@@ -29,6 +29,7 @@ struct TrainPlan {
   size_t pool, pool_idx;    // float[B,56,56,64], uint8 arg-max (0..8, 9 = none)
   size_t mean_rstd;         // per conv: mean[cout], rstd[cout] (floats), packed by stat_offset
   size_t sums;              // double[2 * 512] scratch of the statistics / BN-backward reductions
+  size_t red;               // double[kRedBlocks32][2 * 512]: per-workgroup partial sums of one reduction pass (no atomics)
   size_t wpack;             // packed forward weights of all convs
   size_t wpack_d;           // packed data-gradient weights (largest conv)
   size_t wgrad_p;           // packed weight-gradient accumulator (largest conv)
@@ -37,6 +38,19 @@ struct TrainPlan {
   size_t up;                // zero-interleaved gradient of a stride-2 layer
   size_t total;
 };
+
+constexpr int kRedBlocks32 = 512;  // workgroups of a BN reduction pass = rows of the partial-sum table
+
+// split K of conv i's weight gradient over `slices` chunks of `chunk` pixels so that the launch has ~2048 workgroups
+static void wgrad_split(int i, long long M, long long& slices, long long& chunk) {
+  const ConvDesc& d = kConvs[i];
+  const int tiles = i == 0 ? 7 : d.ks * d.ks * (d.cout / 64) * (d.cin / 64);
+  slices = (2048 + tiles - 1) / tiles;
+  chunk = (M + slices - 1) / slices;
+  chunk = (chunk + 31) / 32 * 32;
+  if (chunk < 256) chunk = 256;
+  slices = (M + chunk - 1) / chunk;
+}
 
 static TrainPlan make_train_plan(int B) {
   TrainPlan p;
@@ -60,11 +74,19 @@ static TrainPlan make_train_plan(int B) {
   p.pool_idx = take(b * 56 * 56 * 64);
   p.mean_rstd = take(stat_offset(kNumConvs) * 4);
   p.sums = take(2 * 512 * 8);
+  p.red = take((size_t)kRedBlocks32 * 1024 * 8);
   size_t wtot = 0;
   for (int i = 0; i < kNumConvs; ++i) wtot += packed_w_floats(i);
   p.wpack = take(wtot * 4);
   p.wpack_d = take(maxw * 4);
-  p.wgrad_p = take(maxw * 4);
+  size_t maxpart = 0;  // split-K partials of a weight gradient: [slices][packed weights], summed in slice order afterwards
+  for (int i = 0; i < kNumConvs; ++i) {
+    long long sl, ch;
+    wgrad_split(i, (long long)b * kConvs[i].hout * kConvs[i].hout, sl, ch);
+    const size_t pf = i == 0 ? (size_t)7 * 64 * 32 : conv_w_floats(i);
+    if ((size_t)sl * (i == 0 ? 2 : 1) * pf > maxpart) maxpart = (size_t)sl * (i == 0 ? 2 : 1) * pf;
+  }
+  p.wgrad_p = take(maxpart * 4);
   p.zero_bias = take(512 * 4);
   for (int k = 0; k < 3; ++k) p.g[k] = take(maxact * 4);
   p.up = take(b * 56 * 56 * 128 * 4);  // largest: layer2 entry (128 ch at 56 x 56)
@@ -116,7 +138,8 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   dw[gid] = accumulate ? dw[gid] + v : v;
 }
 
-// per-channel sum and sum of squares over M rows of an [M][C] map (C % 4 == 0), fp64 atomics
+// per-channel sum and sum of squares over M rows of an [M][C] map (C % 4 == 0): workgroup b leaves its fp64 partial sums in
+// part[b][0..C) and part[b][512..512+C); bn_sum_parts32_kernel adds the rows in a fixed order (no atomics: the step is reproducible)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C,
                                                        double* __restrict__ sums) {
   const int c4 = C >> 2;               // float4 groups per row
@@ -148,10 +171,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     for (int k = 0; k < 4; ++k) {
       double a = 0, b = 0;
       for (int rr = 0; rr < rows_per_pass; ++rr) a += red[0][rr * c4 + tid][k], b += red[1][rr * c4 + tid][k];
-      atomicAdd(&sums[4 * tid + k], a);
-      atomicAdd(&sums[512 + 4 * tid + k], b);
+      sums[(size_t)blockIdx.x * 1024 + 4 * tid + k] = a;
+      sums[(size_t)blockIdx.x * 1024 + 512 + 4 * tid + k] = b;
     }
   }
+}
+
+// partial sums -> sums[c], sums[512 + c] in a FIXED order: lane l of the channel's 32 adds blocks l, l + 32, ... in turn, then a
+// shuffle tree; 8 channels per workgroup
+__global__ __launch_bounds__(256) void bn_sum_parts32_kernel(const double* __restrict__ part, int nblocks, int C,
+                                                             double* __restrict__ sums) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = l; k < nblocks; k += 32) a += part[(size_t)k * 1024 + c], b += part[(size_t)k * 1024 + 512 + c];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) a += __shfl_down(a, o, 32), b += __shfl_down(b, o, 32);
+  if (c < C && l == 0) sums[c] = a, sums[512 + c] = b;
 }
 
 // sums -> mean, rstd (biased variance, as the normalisation uses); running statistics updated with the unbiased one
@@ -235,8 +271,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int k = 0; k < 4; ++k) {
       double a = 0, b = 0;
       for (int rr = 0; rr < rows_per_pass; ++rr) a += red[0][rr * c4 + tid][k], b += red[1][rr * c4 + tid][k];
-      atomicAdd(&sums[4 * tid + k], a);
-      atomicAdd(&sums[512 + 4 * tid + k], b);
+      sums[(size_t)blockIdx.x * 1024 + 4 * tid + k] = a;
+      sums[(size_t)blockIdx.x * 1024 + 512 + 4 * tid + k] = b;
     }
   }
 }
@@ -396,7 +432,8 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // One workgroup = one 64 x 64 (co x ci) tile of one filter tap over a contiguous chunk of output pixels
 // (split-K over the grid's y dimension); 4 waves = 2 x 2 MFMA tiles of 32 x 32 on v_mfma_f32_32x32x2_f32
 // (A = dY[pixel][co], B = X[pixel][ci]: both operands are read along the channel axis, coalesced, no
-// transpose); operands staged through LDS 32 pixels at a time; fp32 atomics (128-byte rows) at the end.
+// transpose); operands staged through LDS 32 pixels at a time; every slice stores its tile into its OWN copy of the packed
+// gradient (dWp + slice * per_slice) and wgrad_reduce32_kernel adds the slices in a fixed order: no atomics.
 // STEM form: X is the padded NHWC4 input, the "ci" axis of a tile is the 32 floats (kw, c) of filter row kh.
 // ---------------------------------------------------------------------------------------------
 template <bool STEM>
@@ -468,11 +505,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
   }
   // D[co][j]: col j = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h
   const int row_len = STEM ? 32 : Cin;
-  float* base = dWp + ((size_t)tap * Cout + cot * 64 + wi * 32) * row_len + (STEM ? 0 : cit * 64 + wj * 32) + r;
+  const size_t per_slice = STEM ? (size_t)7 * 64 * 32 : (size_t)KS * KS * Cout * Cin;
+  // STEM: the two waves of a channel half split the PIXELS of a sub-chunk, i.e. both hold a partial sum of the same tile:
+  // each gets its own copy (slot 2 * slice + wj)
+  const size_t slot = STEM ? (size_t)blockIdx.y * 2 + wj : (size_t)blockIdx.y;
+  float* base = dWp + slot * per_slice + ((size_t)tap * Cout + cot * 64 + wi * 32) * row_len +
+                (STEM ? 0 : cit * 64 + wj * 32) + r;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-    atomicAdd(base + (size_t)row * row_len, acc[e]);
+    base[(size_t)row * row_len] = acc[e];
+  }
+}
+
+// split-K partials -> the PyTorch-layout gradient (accumulate or overwrite).  32 weights per workgroup x 8 slice groups: group g
+// adds slices g, g + 8, ... in turn, then the 8 group sums are added in order -- a fixed order, hence reproducible
+__global__ __launch_bounds__(256) void wgrad_reduce32_kernel(const float* __restrict__ part, int slices, float* __restrict__ dw,
+                                                             int cout, int cin, int ks, int stem, int accumulate) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long gid = (long long)blockIdx.x * 32 + e;
+  const long long total = (long long)cout * cin * ks * ks;
+  float s = 0.f;
+  if (gid < total) {
+    const int kw = (int)(gid % ks);
+    long long t = gid / ks;
+    const int kh = (int)(t % ks);
+    t /= ks;
+    const int ci = (int)(t % cin), co = (int)(t / cin);
+    const size_t per_slice = stem ? (size_t)7 * cout * 32 : (size_t)total;
+    const size_t o = stem ? ((size_t)kh * cout + co) * 32 + kw * 4 + ci : ((size_t)(kh * ks + kw) * cout + co) * cin + ci;
+    for (int k = g; k < slices; k += 8) s += part[(size_t)k * per_slice + o];
+  }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && gid < total) {
+    float v = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += red[k][e];
+    dw[gid] = accumulate ? dw[gid] + v : v;
   }
 }
 
@@ -552,7 +623,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
                                                  const float* __restrict__ cw, int M, int C, float* __restrict__ loss,
                                                  float* __restrict__ dlogits, float* __restrict__ scratch /* [2] */,
                                                  int phase) {
-  // phase 0: scratch[0] = sum w nll, scratch[1] = sum w; phase 1: gradient (needs scratch[1]) and the loss value
+  // phase 0: per-wave (sum w nll, sum w) into scratch[2 ..]; phase 2: their sums in order -> scratch[0], scratch[1];
+  // phase 1: gradient (needs scratch[1]) and the loss value
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (phase == 0) {
     float nll = 0.f, w = 0.f;
@@ -572,7 +644,15 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
       }
     }
     for (int o = 32; o > 0; o >>= 1) nll += __shfl_down(nll, o, 64), w += __shfl_down(w, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&scratch[0], nll), atomicAdd(&scratch[1], w);
+    // every workgroup's four wave sums, then the workgroups in order (phase 2 below): no atomics, a reproducible loss
+    if ((threadIdx.x & 63) == 0) scratch[2 + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = nll, scratch[3 + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = w;
+  } else if (phase == 2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float a = 0.f, b = 0.f;
+      const int nw = 4 * ((M + 255) / 256);
+      for (int k = 0; k < nw; ++k) a += scratch[2 + 2 * k], b += scratch[3 + 2 * k];
+      scratch[0] = a, scratch[1] = b;
+    }
   } else if (m < M) {
     const float* l = logits + (size_t)m * C;
     float mx = l[0];
@@ -692,11 +772,12 @@ static int bn_forward(const BnCtx& c, int i, int n, const float* resid, int relu
   float* mean = (float*)(c.ws + c.p->mean_rstd) + stat_offset(i);
   float* rstd = mean + d.cout;
   const float* gamma = c.params + param_offset(i) + conv_w_floats(i);
-  HIPAC_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * 512 * 8, c.s));
+  double* part = (double*)(c.ws + c.p->red);
   const int rows_per_pass = 256 / (d.cout / 4);
   long long gs = (M + rows_per_pass - 1) / rows_per_pass;
-  if (gs > 512) gs = 512;  // 2 workgroups per CU: every workgroup ends in 2 C fp64 atomics on the same C addresses
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, x, M, d.cout, sums);
+  if (gs > kRedBlocks32) gs = kRedBlocks32;  // 2 workgroups per CU
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, x, M, d.cout, part);
+  hipLaunchKernelGGL(bn_sum_parts32_kernel, dim3((d.cout + 7) / 8), dim3(256), 0, c.s, (const double*)part, (int)gs, d.cout, sums);
   float* rm = c.stats ? c.stats + stat_offset(i) : nullptr;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((d.cout + 255) / 256), dim3(256), 0, c.s, (const double*)sums, M, d.cout, c.eps,
                      c.momentum, mean, rstd, rm, rm ? rm + d.cout : nullptr);
@@ -717,11 +798,12 @@ static int bn_backward(const BnCtx& c, int i, int n, const float* dy, const floa
   const float* rstd = mean + d.cout;
   const float* gamma = c.params + param_offset(i) + conv_w_floats(i);
   float* dgamma = grads + param_offset(i) + conv_w_floats(i);
-  HIPAC_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * 512 * 8, c.s));
+  double* part = (double*)(c.ws + c.p->red);
   const int rows_per_pass = 256 / (d.cout / 4);
   long long gs = (M + rows_per_pass - 1) / rows_per_pass;
-  if (gs > 512) gs = 512;  // 2 workgroups per CU: every workgroup ends in 2 C fp64 atomics on the same C addresses
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, dy, x, ymask, M, d.cout, mean, rstd, sums);
+  if (gs > kRedBlocks32) gs = kRedBlocks32;  // 2 workgroups per CU
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gs), dim3(256), 0, c.s, dy, x, ymask, M, d.cout, mean, rstd, part);
+  hipLaunchKernelGGL(bn_sum_parts32_kernel, dim3((d.cout + 7) / 8), dim3(256), 0, c.s, (const double*)part, (int)gs, d.cout, sums);
   const long long n4 = M * d.cout / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, c.s, dy, x, ymask, dx, n4, M, d.cout, mean, rstd,
                      gamma, (const double*)sums, dgamma, dgamma + d.cout, accumulate);
@@ -734,15 +816,9 @@ static int conv_wgrad(const BnCtx& c, int i, int n, const float* X, const float*
   float* dwp = (float*)(c.ws + c.p->wgrad_p);
   const long long M = (long long)n * d.hout * d.hout;
   const bool stem = i == 0;
-  const size_t pf = stem ? (size_t)7 * 64 * 32 : conv_w_floats(i);
-  HIPAC_CHECK_HIP(hipMemsetAsync(dwp, 0, pf * 4, c.s));
   const int tiles = stem ? 7 : d.ks * d.ks * (d.cout / 64) * (d.cin / 64);
-  // split K so that the launch has ~2048 workgroups, chunks a multiple of 32 pixels
-  long long slices = (2048 + tiles - 1) / tiles;
-  long long chunk = (M + slices - 1) / slices;
-  chunk = (chunk + 31) / 32 * 32;
-  if (chunk < 256) chunk = 256;
-  slices = (M + chunk - 1) / chunk;
+  long long slices, chunk;
+  wgrad_split(i, M, slices, chunk);  // the workspace plan sized dwp for exactly this split
   if (stem)
     hipLaunchKernelGGL((wgrad_kernel<true>), dim3(tiles, (unsigned)slices), dim3(256), 0, c.s, dY, X, dwp, 64, 3, 7, 2, 112, 224,
                        M, (int)chunk);
@@ -750,7 +826,8 @@ static int conv_wgrad(const BnCtx& c, int i, int n, const float* X, const float*
     hipLaunchKernelGGL((wgrad_kernel<false>), dim3(tiles, (unsigned)slices), dim3(256), 0, c.s, dY, X, dwp, d.cout, d.cin, d.ks,
                        d.stride, d.hout, d.hin, M, (int)chunk);
   const long long total = (long long)conv_w_floats(i);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, (const float*)dwp,
+  hipLaunchKernelGGL(wgrad_reduce32_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, c.s, (const float*)dwp,
+                     (int)(stem ? 2 * slices : slices),
                      grads + param_offset(i), d.cout, d.cin, d.ks, stem ? 1 : 0, accumulate);
   return (int)hipGetLastError();
 }
@@ -973,15 +1050,15 @@ int hipac_linear_backward(const float* x, const float* w, const float* dy, const
   return 0;
 }
 
-// nn.CrossEntropyLoss(weight=class_w) value and gradient (src/main.py:490, :552-566); scratch: float[2]
+// nn.CrossEntropyLoss(weight=class_w) value and gradient (src/main.py:490, :552-566); scratch: float[2 + 8 * ceil(M / 256)]
 int hipac_cross_entropy_fwd_bwd(const float* logits, const int64_t* labels, const float* class_w, int M, int C, float* loss,
                                 float* dlogits, float* scratch, void* stream) {
   HIPAC_REQUIRE(logits && labels && loss && dlogits && scratch && M > 0 && C > 0 && C <= 64, HIPAC_EINVAL,
                 "cross_entropy: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  HIPAC_CHECK_HIP(hipMemsetAsync(scratch, 0, 8, s));
   hipLaunchKernelGGL(ce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logits, (const long long*)labels, class_w, M, C, loss,
                      dlogits, scratch, 0);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(64), 0, s, logits, (const long long*)labels, class_w, M, C, loss, dlogits, scratch, 2);
   hipLaunchKernelGGL(ce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logits, (const long long*)labels, class_w, M, C, loss,
                      dlogits, scratch, 1);
   HIPAC_CHECK_HIP(hipGetLastError());

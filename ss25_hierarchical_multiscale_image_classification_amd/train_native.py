@@ -398,7 +398,7 @@ class NativeClassifierTrainer:
         self.fc = NativeLinear(self.head, 0, C_, 512)
         self.fc.w.copy_(bare["fc.weight"]), self.fc.b.copy_(bare["fc.bias"])
         self.class_weights = None if class_weights is None else class_weights.to(self.device, torch.float32).contiguous()
-        self._scratch = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._scratch = torch.zeros(2 + 8 * 64, dtype=torch.float32, device=self.device)  # hipac_cross_entropy_fwd_bwd: batches <= 16 384
 
     def forward_backward(self, x: torch.Tensor, labels: torch.Tensor):
         """(loss, logits of this rank).  N > 1: the loss is CrossEntropyLoss(weight) over the GLOBAL batch, as the

@@ -91,7 +91,7 @@ def test_linear_cross_entropy_adam_against_torch():
         loss_r = torch.nn.functional.cross_entropy(lr_, labels, weight=cw)
         loss_r.backward()
         ld, lab = logits.to(dev), labels.to(dev)
-        loss, dl, scratch = torch.empty((), device=dev), torch.empty_like(ld), torch.zeros(2, device=dev)
+        loss, dl, scratch = torch.empty((), device=dev), torch.empty_like(ld), torch.zeros(2 + 8 * 2, device=dev)
         capi._check(lib.hipac_cross_entropy_fwd_bwd(ld.data_ptr(), lab.data_ptr(), None if cw is None else cw.to(dev).data_ptr(),
                                                     300, 3, loss.data_ptr(), dl.data_ptr(), scratch.data_ptr(), capi._stream()), "ce")
         assert abs(float(loss) - float(loss_r)) < 1e-5 and rel(dl, lr_.grad) < 1e-5
@@ -301,3 +301,32 @@ def test_two_rank_simclr_step(tmp_path):
     # the check here is the collective semantics -- loss, and the gradients nearest to the loss
     for k in ("projector.2.weight", "projector.2.bias", "projector.0.weight", "projector.0.bias"):
         assert rel(res[0]["grads"][k], ref[k]) <= 5e-3, (k, rel(res[0]["grads"][k], ref[k]))
+
+
+def test_fp32_steps_run_twice_give_the_same_bits():
+    """The fp32 steps reduce without atomics too (BN statistics and their backward sums through per-workgroup partials added
+    in a fixed order, the weight gradients' split-K slices likewise, the cross-entropy sums per wave): the same SimCLR step and
+    the same classifier step from the same state give the same parameters bit for bit, the loss included."""
+    from ss25_hierarchical_multiscale_image_classification_amd.resnet import ResNet18Classifier
+
+    torch.manual_seed(23)
+    sd = {k: v.clone() for k, v in SimCLRModel().state_dict().items()}
+    x_i, x_j = torch.randn(12, 3, 224, 224).cuda(), torch.randn(12, 3, 224, 224).cuda()
+    outs = []
+    for _ in range(2):
+        tr = TN.NativeSimCLRTrainer(sd, device="cuda", lr=1e-3, precision="fp32")
+        l1, l2 = float(tr.step(x_i, x_j)), float(tr.step(x_j, x_i))
+        outs.append((l1, l2, tr.state_dict()))
+    assert outs[0][:2] == outs[1][:2]
+    for k, v in outs[0][2].items():
+        assert torch.equal(v, outs[1][2][k]), k
+    csd = {k: v.clone() for k, v in ResNet18Classifier().state_dict().items()}
+    x, y = torch.randn(300, 3, 224, 224).cuda(), torch.randint(0, 2, (300,))
+    outs = []
+    for _ in range(2):
+        tr = TN.NativeClassifierTrainer(csd, device="cuda", lr=1e-4, class_weights=torch.tensor([1.0, 2.5]), precision="fp32")
+        loss, logits = tr.step(x, y)
+        outs.append((float(loss), logits.cpu(), tr.state_dict()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    for k, v in outs[0][2].items():
+        assert torch.equal(v, outs[1][2][k]), k
