@@ -23,8 +23,11 @@
 
 namespace hipac {
 
+// TKH / TKW / UPS: the parity-class data gradient of a stride-2 convolution (training), see conv_glds_kernel's note: the input is the
+// gradient on the coarse grid, the window TKH x TKW taps starting at the output pixel, no padding, output pixel (y, x) stored at
+// (2y + PY, 2x + PX) of the fine grid, UPS = 4 | PY << 1 | PX.
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, int BN, bool RELU,
-          bool RESID, bool OUTF32, bool STEM>
+          bool RESID, bool OUTF32, bool STEM, int TKH = 0, int TKW = 0, int UPS = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ in,
                                                          const T* __restrict__ wgt,
                                                          const float* __restrict__ bias,
@@ -32,11 +35,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
                                                          void* __restrict__ outp, int M) {
   using E = Elem<T>;
   using frag = typename E::frag;
-  constexpr int PAD = STEM ? 0 : KS / 2;
-  constexpr int HO = STEM ? 112 : (HI + 2 * PAD - KS) / STRIDE + 1;
-  constexpr int WO = STEM ? 112 : (WI + 2 * PAD - KS) / STRIDE + 1;
+  constexpr int KH = UPS ? TKH : KS, KW = UPS ? TKW : KS;
+  constexpr int PAD = (STEM || UPS) ? 0 : KS / 2;
+  constexpr int HO = STEM ? 112 : (UPS ? HI : (HI + 2 * PAD - KS) / STRIDE + 1);
+  constexpr int WO = STEM ? 112 : (UPS ? WI : (WI + 2 * PAD - KS) / STRIDE + 1);
+  static_assert(!UPS || (!STEM && STRIDE == 1 && TKH >= 1 && TKW >= 1 && !RESID), "parity-class data gradient");
   constexpr int BK = STEM ? 32 : 64;
-  constexpr int KT = STEM ? 7 : KS * KS * (CIN / 64);
+  constexpr int KT = STEM ? 7 : KH * KW * (CIN / 64);
   constexpr int KTOT = KT * BK;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk: 8 (bf16/fp16) or 4 (fp32)
   constexpr int LDA = BK + EPC;             // LDS row padded by one chunk, elements
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
       cc = 0;
       if constexpr (STEM) {
         ++kh;
-      } else if (++kw == KS) {
+      } else if (++kw == KW) {
         kw = 0;
         ++kh;
       }
@@ -180,7 +185,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const T* __restrict__ i
         float v1 = acc[i][j][4 * q + 1] + bv.y;
         float v2 = acc[i][j][4 * q + 2] + bv.z;
         float v3 = acc[i][j][4 * q + 3] + bv.w;
-        const size_t o = (size_t)m * COUT + c0;
+        size_t o = (size_t)m * COUT + c0;
+        if constexpr (UPS != 0) {  // coarse pixel m = (b, y, x) -> fine position (2y + PY, 2x + PX)
+          const int ub = m / (HO * WO), urem = m - ub * (HO * WO), uy = urem / WO, ux = urem - uy * WO;
+          o = ((size_t)(ub * 2 * HO + 2 * uy + ((UPS >> 1) & 1)) * (2 * WO) + 2 * ux + (UPS & 1)) * COUT + c0;
+        }
         if constexpr (RESID) {
           const typename E::vec4 rv = *reinterpret_cast<const typename E::vec4*>(resid + o);
           v0 += (float)rv[0];
@@ -2769,6 +2778,27 @@ static int launch_dgrad_s2(const void* g, const void* wc, const float* zero_bias
   if (int rc = launch_dgrad_s2_class<T, CG, CX, HC, 1, 2, 0, 1>(g, w + blk, zero_bias, dx, n, s, zero_page)) return rc;
   if (int rc = launch_dgrad_s2_class<T, CG, CX, HC, 2, 1, 1, 0>(g, w + 3 * blk, zero_bias, dx, n, s, zero_page)) return rc;
   return launch_dgrad_s2_class<T, CG, CX, HC, 2, 2, 1, 1>(g, w + 5 * blk, zero_bias, dx, n, s, zero_page);
+}
+
+// the same four classes on the v1 kernel (the fp32 training step: exact f32 MFMA)
+template <typename T, int CG, int CX, int HC, int TKH, int TKW, int PY, int PX>
+static int launch_dgrad_s2_class_v1(const void* g, const void* wc, const float* zero_bias, void* dx, int n, hipStream_t s) {
+  constexpr int BN = 64;
+  const int M = n * HC * HC;
+  dim3 grid((M + 127) / 128, CX / BN);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, CG, CX, HC, HC, 1, 1, BN, false, false, false, false, TKH, TKW, 4 | (PY << 1) | PX>), grid,
+                     dim3(256), 0, s, (const T*)g, (const T*)wc, zero_bias, (const T*)nullptr, dx, M);
+  return (int)hipGetLastError();
+}
+template <typename T, int CG, int CX, int HC, bool KS3>
+static int launch_dgrad_s2_v1(const void* g, const void* wc, const float* zero_bias, void* dx, int n, hipStream_t s) {
+  const T* w = (const T*)wc;
+  constexpr size_t blk = (size_t)CX * CG;
+  if constexpr (!KS3) return launch_dgrad_s2_class_v1<T, CG, CX, HC, 1, 1, 0, 0>(g, w, zero_bias, dx, n, s);
+  if (int rc = launch_dgrad_s2_class_v1<T, CG, CX, HC, 1, 1, 0, 0>(g, w, zero_bias, dx, n, s)) return rc;
+  if (int rc = launch_dgrad_s2_class_v1<T, CG, CX, HC, 1, 2, 0, 1>(g, w + blk, zero_bias, dx, n, s)) return rc;
+  if (int rc = launch_dgrad_s2_class_v1<T, CG, CX, HC, 2, 1, 1, 0>(g, w + 3 * blk, zero_bias, dx, n, s)) return rc;
+  return launch_dgrad_s2_class_v1<T, CG, CX, HC, 2, 2, 1, 1>(g, w + 5 * blk, zero_bias, dx, n, s);
 }
 
 #ifndef HIPAC_USE_S2C64

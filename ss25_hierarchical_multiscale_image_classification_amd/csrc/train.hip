@@ -105,6 +105,7 @@ static size_t wpack_offset(int i) {
 // mode 0: forward pack  dst[co][(kh*ks+kw)*cin + ci]        = w[co][ci][kh][kw]
 // mode 1: data-gradient dst[ci][((ks-1-kh)*ks + ks-1-kw)*cout + co] = w[co][ci][kh][kw]
 // mode 2: stem          dst[co][kh*32 + kw*4 + ci] (row of 224, rest zero: the caller clears dst)
+// mode 3: data gradient of a 3x3 / stride 2 conv, four parity-class blocks (see below)
 __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout,
                                                      int cin, int ks, int mode) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -118,7 +119,14 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ w
   const float v = w[gid];
   if (mode == 0) dst[(size_t)co * ks * ks * cin + (size_t)(kh * ks + kw) * cin + ci] = v;
   else if (mode == 1) dst[(size_t)ci * ks * ks * cout + (size_t)((ks - 1 - kh) * ks + ks - 1 - kw) * cout + co] = v;
-  else dst[(size_t)co * 224 + kh * 32 + kw * 4 + ci] = v;
+  else if (mode == 3) {
+    // data gradient of a 3x3 / stride 2 conv by parity class (launch_dgrad_s2_v1, conv_igemm.h): class (py, px) = (kh != 1, kw != 1),
+    // taps (a, b) = ((2 - kh) / 2, (2 - kw) / 2); blocks of 1, 2, 2, 4 taps back to back, each [ci][tap][co]
+    const int py = kh != 1, px = kw != 1, a = py ? (2 - kh) / 2 : 0, b = px ? (2 - kw) / 2 : 0;
+    const int ntap = (py ? 2 : 1) * (px ? 2 : 1), tap = a * (px ? 2 : 1) + b;
+    const size_t blk = (size_t)cin * cout, off = (py ? 3 : 0) * blk + (px ? (py ? 2 : 1) : 0) * blk;
+    dst[off + (size_t)ci * ntap * cout + (size_t)tap * cout + co] = v;
+  } else dst[(size_t)co * 224 + kh * 32 + kw * 4 + ci] = v;
 }
 
 // packed weight gradient -> PyTorch layout (accumulate or overwrite).  generic: src[tap][co][ci];
@@ -745,6 +753,26 @@ static int conv_dgrad(int i, const float* g, const float* wd, const float* zb, f
   }
 }
 
+#ifndef HIPAC_F32_DGRAD_CLASSES
+#define HIPAC_F32_DGRAD_CLASSES 1  // stride-2 data gradients by parity class (a quarter of the MFMAs); 0: the zero-interleaved form
+#endif
+// data gradient of a STRIDE-2 conv i by parity classes: g on the coarse grid, weights in mode 3 (3x3) or 1 (1x1; `out` zeroed)
+static int conv_dgrad_s2(int i, const float* g, const float* wd, const float* zb, float* out, int n, hipStream_t s) {
+  const ConvDesc& d = kConvs[i];
+  if (d.ks == 3) {
+    switch (d.cout) {
+      case 128: return launch_dgrad_s2_v1<float, 128, 64, 28, true>(g, wd, zb, out, n, s);
+      case 256: return launch_dgrad_s2_v1<float, 256, 128, 14, true>(g, wd, zb, out, n, s);
+      default: return launch_dgrad_s2_v1<float, 512, 256, 7, true>(g, wd, zb, out, n, s);
+    }
+  }
+  switch (d.cout) {
+    case 128: return launch_dgrad_s2_v1<float, 128, 64, 28, false>(g, wd, zb, out, n, s);
+    case 256: return launch_dgrad_s2_v1<float, 256, 128, 14, false>(g, wd, zb, out, n, s);
+    default: return launch_dgrad_s2_v1<float, 512, 256, 7, false>(g, wd, zb, out, n, s);
+  }
+}
+
 static int pack_weights(const float* w, float* dst, int i, int mode, hipStream_t s) {
   const ConvDesc& d = kConvs[i];
   const long long total = (long long)conv_w_floats(i);
@@ -982,20 +1010,34 @@ int hipac_train_encoder_backward(const float* params, const float* dfeats, int b
       TRY(conv_dgrad(c2, gB, wd, zb, gC, n, s));                                       // gC = d post(c1) (before its ReLU mask)
       TRY(bn_backward(c, c1, n, gC, post(c1), gC, grads, accumulate));                 // gC = d pre(c1)
       TRY(conv_wgrad(c, c1, n, xin_blk, gC, grads, accumulate));
-      TRY(pack_weights(params + param_offset(c1), wd, c1, 1, s));
-      const float* g1 = gC;
-      if (d1.stride == 2) {
-        const long long nu4 = (long long)n * d1.hin * d1.hin * d1.cout / 4;
-        hipLaunchKernelGGL(upsample_zero_kernel, dim3(grid_for(nu4)), dim3(256), 0, s, (const float*)gC, up, nu4, d1.hout, d1.cout);
-        TRY((int)hipGetLastError());
-        g1 = up;
+      if (d1.stride == 2 && HIPAC_F32_DGRAD_CLASSES) {
+        TRY(pack_weights(params + param_offset(c1), wd, c1, 3, s));
+        TRY(conv_dgrad_s2(c1, gC, wd, zb, gB, n, s));                                  // gB = d block input via the main path
+      } else {
+        TRY(pack_weights(params + param_offset(c1), wd, c1, 1, s));
+        const float* g1 = gC;
+        if (d1.stride == 2) {
+          const long long nu4 = (long long)n * d1.hin * d1.hin * d1.cout / 4;
+          hipLaunchKernelGGL(upsample_zero_kernel, dim3(grid_for(nu4)), dim3(256), 0, s, (const float*)gC, up, nu4, d1.hout, d1.cout);
+          TRY((int)hipGetLastError());
+          g1 = up;
+        }
+        TRY(conv_dgrad(c1, g1, wd, zb, gB, n, s));                                     // gB = d block input via the main path
       }
-      TRY(conv_dgrad(c1, g1, wd, zb, gB, n, s));                                       // gB = d block input via the main path
       // --- identity path
       if (down) {
         TRY(bn_backward(c, ds, n, gA, nullptr, gC, grads, accumulate));                // gC = d pre(ds)
         TRY(conv_wgrad(c, ds, n, xin_blk, gC, grads, accumulate));
         TRY(pack_weights(params + param_offset(ds), wd, ds, 1, s));
+        if (HIPAC_F32_DGRAD_CLASSES) {
+          // 1x1 / stride 2: only the even positions of the fine grid receive a gradient; `up` takes it (gC holds the input)
+          HIPAC_CHECK_HIP(hipMemsetAsync(up, 0, (size_t)n * d1.hin * d1.hin * kConvs[ds].cin * 4, s));
+          TRY(conv_dgrad_s2(ds, gC, wd, zb, up, n, s));
+          hipLaunchKernelGGL(add_mask_kernel, dim3(grid_for(n_in4)), dim3(256), 0, s, (const float*)gB, (const float*)up, prev_post,
+                             gA, n_in4);
+          TRY((int)hipGetLastError());
+          continue;
+        }
         const long long nu4 = (long long)n * d1.hin * d1.hin * kConvs[ds].cout / 4;
         hipLaunchKernelGGL(upsample_zero_kernel, dim3(grid_for(nu4)), dim3(256), 0, s, (const float*)gC, up, nu4, kConvs[ds].hout,
                            kConvs[ds].cout);
