@@ -281,7 +281,7 @@ int hipac_mil_forward(const hipac_mil_params_t* params, int pooling, const float
  * NT-Xent loss of the SimCLR step, value and gradient in one call (SURVEY a-12).
  * Replaces nt_xent_loss, src/models/simclr.py:31-54, and its autograd backward:
  * z = cat(z_i, z_j) float32 [2n][d] (device), loss float32[1] (device),
- * dz float32 [2n][d] = d loss / d z (NULL: value only).  d <= 256.
+ * dz float32 [2n][d] = d loss / d z (NULL: value only).  n <= 16384; the scratch holds the [2n][2n] similarity matrix.
  * scratch: hipac_ntxent_scratch_bytes(n, d) bytes of device memory.
  * ------------------------------------------------------------------------- */
 size_t hipac_ntxent_scratch_bytes(int n, int d);

@@ -149,6 +149,10 @@ int run_trunk_f16x3(const Net& net, const Plan& p, char* ws, const void* xin, in
                     hipStream_t s, int first, int last);
 int launch_u8_to_nhwc4_f32(const unsigned char* x, const float* lut, float* out, int n, hipStream_t s);
 
+// train.hip: strided fp32 GEMM on the f32 MFMA, C[m][n] = sum_k a[m*sam + k*sak] * b[n*sbn + k*sbk]
+int launch_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbn, long long sbk, float* c, long long ldc,
+                    int M, int N, int K, hipStream_t s);
+
 // elementwise.hip
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);
 int launch_head(const float* last, int n, const float* fc_w, const float* fc_b, int num_classes,

@@ -1064,6 +1064,18 @@ int hipac_train_encoder_backward(const float* params, const float* dfeats, int b
   return 0;
 }
 
+}  // extern "C"
+namespace hipac {
+// the strided f32-MFMA GEMM for the other translation units (ntxent.hip): C[m][n] = sum_k A(m,k) B(n,k)
+int launch_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbn, long long sbk, float* c, long long ldc,
+                    int M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((M + 63) / 64, (N + 63) / 64), dim3(256), 0, s, a, sam, sak, b, sbn, sbk, c, ldc, M, N, K,
+                     (const float*)nullptr, 0, 0);
+  return (int)hipGetLastError();
+}
+}  // namespace hipac
+extern "C" {
+
 // y[M][N] = x[M][K] w[N][K]^T + b (ReLU)    -- nn.Linear forward (src/models/simclr.py:20-24 projector, resnet.py:66 fc)
 int hipac_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, void* stream) {
   HIPAC_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, HIPAC_EINVAL, "linear_forward: bad argument");

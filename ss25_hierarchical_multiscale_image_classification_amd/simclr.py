@@ -65,12 +65,12 @@ def nt_xent_loss(z_i: torch.Tensor, z_j: torch.Tensor, temperature: float = 0.5,
                  backend: Optional[str] = None) -> torch.Tensor:
     """src/models/simclr.py:31-54.  ``gather`` (optional) maps the local [n,D] block to
     the global [N,D] one, differentiably, before the loss.  ``backend``: "hip" (the native
-    kernel; default for float32 ROCm tensors with D <= 256), "torch" (the reference's own
+    kernel; default for float32 ROCm tensors with D <= 4096), "torch" (the reference's own
     formula on any device)."""
     if gather is not None:
         z_i, z_j = gather(z_i), gather(z_j)
     if backend is None:
-        backend = "hip" if (z_i.is_cuda and z_i.dtype == torch.float32 and z_i.shape[1] <= 256) else "torch"
+        backend = "hip" if (z_i.is_cuda and z_i.dtype == torch.float32 and z_i.shape[1] <= 4096) else "torch"
     if backend == "hip":
         return _NTXentHip.apply(torch.cat([z_i, z_j], dim=0), float(temperature))
     n = z_i.size(0)
