@@ -572,15 +572,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // this thread's 8 + 8 elements of a K tile: rows row0 + 8 j, column kk; the NEXT tile is fetched into registers behind the MFMAs
+  const int kk_t = tid & 31, row0 = tid >> 5;
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
+    const int k = k0 + kk_t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + row0 + 8 * j, n = n0 + row0 + 8 * j;
+      ra[j] = (m < M && k < K) ? a[m * sam + k * sak] : 0.f;
+      rb[j] = (n < N && k < K) ? b[n * sbn + k * sbk] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += 32) {
     __syncthreads();
-    for (int i = tid; i < 64 * 32; i += 256) {
-      const int row = i >> 5, kk = i & 31;
-      const int m = m0 + row, n = n0 + row, k = k0 + kk;
-      As[row * LDP + kk] = (m < M && k < K) ? a[m * sam + k * sak] : 0.f;
-      Bs[row * LDP + kk] = (n < N && k < K) ? b[n * sbn + k * sbk] : 0.f;
-    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) As[(row0 + 8 * j) * LDP + kk_t] = ra[j], Bs[(row0 + 8 * j) * LDP + kk_t] = rb[j];
     __syncthreads();
+    if (k0 + 32 < K) fetch(k0 + 32);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(wi * 32 + r) * LDP + 2 * kk + h], Bs[(wj * 32 + r) * LDP + 2 * kk + h],
