@@ -463,7 +463,7 @@ static bool derive(const unsigned char* bits, const unsigned char* vals, DevHuff
   p = 0;
   while (huffsize[p]) {
     while ((int)huffsize[p] == si) huffcode[p++] = code++;
-    if ((int)code > (1 << si)) return false;
+    if ((int)code >= (1 << si)) return false;  // jdhuff.c: no code may be all ones
     code <<= 1;
     ++si;
   }
