@@ -2021,7 +2021,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 //     wave's private fp32 staging rows and leaves as 16-byte items, 64 contiguous bytes per
 //     pixel; the residual items are prefetched into registers one sub-tile ahead
 // ---------------------------------------------------------------------------------------
-template <typename T, bool RESID>
+template <typename T, bool RESID, bool RELU = true>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                              const float* __restrict__ bias,
                                                              const T* __restrict__ resid, T* __restrict__ out,
@@ -2246,7 +2246,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const T* __restrict
         }
         frag ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (T)fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) ov[e] = (T)(RELU ? fmaxf(v[e], 0.f) : v[e]);  // (training's convolutions carry no ReLU: BN follows)
         if (tile_ok) *reinterpret_cast<frag*>(out + item_off(i, ki)) = ov;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads returned before it is overwritten
@@ -2641,11 +2641,11 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     dim3 grid((M + 127) / 128, COUT / BN);
     hipLaunchKernelGGL((conv_igemm_kernel<T, CIN, COUT, HI, WI, KS, STRIDE, BN, RELU, RESID, OUTF32, STEM>),
                        grid, dim3(256), 0, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M);
-  } else if constexpr (HIPAC_USE_C64 && !SPLIT && KS == 3 && STRIDE == 1 && CIN == 64 && COUT == 64 && HI == 56 && RELU && !OUTF32) {
+  } else if constexpr (HIPAC_USE_C64 && !SPLIT && KS == 3 && STRIDE == 1 && CIN == 64 && COUT == 64 && HI == 56 && !OUTF32) {
     const int n_tiles = n * 49;
     const int n_units = (n_tiles + 1) / 2;
     const int grid = n_units < 512 ? n_units : 512;  // persistent, 2 workgroups per CU
-    hipLaunchKernelGGL((conv3x3_c64_kernel<T, RESID>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w,
+    hipLaunchKernelGGL((conv3x3_c64_kernel<T, RESID, RELU>), dim3(grid), dim3(256), 0, s, (const T*)in, (const T*)w.w,
                        w.bias, (const T*)resid, (T*)out, n_tiles, zero_page);
   } else if constexpr (HIPAC_USE_HALO && HIPAC_HALO_BIG && !SPLIT && KS == 3 && STRIDE == 1 && COUT >= 128) {
     // one 512-register wave per SIMD, each wave a 128 pixel x 128 channel tile
