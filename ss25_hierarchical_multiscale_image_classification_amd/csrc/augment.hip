@@ -124,7 +124,9 @@ __device__ __forceinline__ void rgb2hsv8(int r, int g, int b, int& uh, int& us, 
   if (r == maxc) hf = __fsub_rn(bc, gc);
   else if (g == maxc) hf = (float)__dsub_rn(__dadd_rn(2.0, (double)rc), (double)bc);
   else hf = (float)__dsub_rn(__dadd_rn(4.0, (double)gc), (double)rc);
-  const double hd = fmod(__dadd_rn(__ddiv_rn((double)hf, 6.0), 1.0), 1.0);
+  // fmod(x, 1.0) for x = h / 6 + 1 in [1/6, 17/6): x - floor(x), exact in floating point
+  const double hx = __dadd_rn(__ddiv_rn((double)hf, 6.0), 1.0);
+  const double hd = hx - floor(hx);
   const float h = (float)hd;
   uh = clip8i((int)__dmul_rn((double)h, 255.0));
   us = clip8i((int)__dmul_rn((double)s, 255.0));
