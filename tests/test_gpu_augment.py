@@ -78,9 +78,9 @@ def test_hue_over_the_whole_colour_cube():
         assert np.array_equal(got.cpu().numpy(), ref), hf
 
 
-@pytest.mark.parametrize("P", [224, 448, 896])
+@pytest.mark.parametrize("P", [224, 448, 896, 1792])
 def test_resized_crop_and_flip_equal_pillow(P):
-    imgs = _images(4, P, 5 + P)
+    imgs = _images(4 if P < 1792 else 2, P, 5 + P)
     pool = augment.DevicePatchPool(imgs.cuda())
     rng = np.random.default_rng(P)
     crops = [(0, 0, P, P), (0, 0, 1, 1), (P - 1, P - 1, 1, 1), (3, 5, P - 3, P - 5), (0, P - 57, P, 57), (P - 60, 0, 60, P), (10, 20, min(223, P - 10), min(225, P - 20))]
