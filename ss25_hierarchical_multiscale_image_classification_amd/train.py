@@ -188,12 +188,18 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     if device_aug:
         # the decoded patches of both sets stay in HBM; flips / rotation / jitter of the tumour patches and the eval transform
         # of the others are made per batch on the device (augment.py); 224-pixel patches only (the level `--train` reads)
-        from .augment import DeviceClassifierLoader, DevicePatchPool
+        from .augment import OUT, DeviceClassifierLoader, DevicePatchPool
 
-        train_loader = DeviceClassifierLoader(DevicePatchPool.from_patch_dataset(train_ds, device=device), batch_size, shuffle=True,
-                                              augment=True, seed=0, rank=rank, world=world)
-        val_loader = DeviceClassifierLoader(DevicePatchPool.from_patch_dataset(val_ds, device=device), batch_size, shuffle=False,
-                                            augment=False, rank=rank, world=world)
+        tr_pool = DevicePatchPool.from_patch_dataset(train_ds, device=device)
+        if tr_pool.P == OUT:
+            train_loader = DeviceClassifierLoader(tr_pool, batch_size, shuffle=True, augment=True, seed=0, rank=rank, world=world)
+            val_loader = DeviceClassifierLoader(DevicePatchPool.from_patch_dataset(val_ds, device=device), batch_size, shuffle=False,
+                                                augment=False, rank=rank, world=world)
+        else:  # the rotation / jitter of train_transform act at the source resolution before the resize: host transforms there
+            if rank == 0:
+                print(f"[INFO] --device_aug: {tr_pool.P}-pixel patches keep the host transforms (the device pipeline of the "
+                      f"classifier loops takes 224-pixel patches)")
+            del tr_pool
     w = class_weights(train_ds, strategy)
     trainer = NativeClassifierTrainer(model.state_dict(), device=dev, lr=lr, class_weights=w, precision=train_precision)
     trainer.sync_from_rank0()
