@@ -1,0 +1,456 @@
+// conv3x3_halo16_kernel: the halo direct convolution of conv_igemm.h (3x3 / stride 1 / pad 1, layers 2-4) on
+// v_mfma_f32_16x16x32_{bf16,f16} instead of 32x32x16 (round 4).  Included by conv_igemm.h.
+//
+// Why a second MFMA shape: under the whole forward this chip sits at its package power limit (sclk ~1.98 GHz of 2.4,
+// DESIGN.md section 3), so cycles per FLOP do not decide the rate -- the clock the chip can hold does, and the guide
+// (MI355X_MICROARCH.md, "DVFS give-back" item 7) measures 1.12-1.14x the FLOP/s for the 16x16x32 shape over 32x32x16
+// on random data with LDS-fed operands at equal cycles.  Same tile, same LDS traffic, same accumulator registers:
+//
+//   workgroup tile 256 pixels x 128 channels, 4 waves (2 x 2), each wave 128 px x 64 ch
+//     = 8 pixel sub-tiles (16 px) x 4 channel sub-tiles (16 ch) = 32 accumulators of 4 registers (128, as before);
+//   a K step of 32 channels = 8 activation + 4 weight fragments (ds_read_b128) for 32 MFMAs
+//     = 0.75 fragment reads per 32x32x16-equivalent, as before.
+//
+// Operands (guide section 3, "A/B operand lane maps"): lane l = (n = l & 15, g = l >> 4) holds A[row n][k = 8 g + j] and
+// B[k = 8 g + j][col n]; D: lane holds rows 4 g .. 4 g + 3 of column n.  Weights are A (rows = output channels),
+// activations B (columns = pixels), so a lane's four accumulator registers are four CONSECUTIVE channels of one pixel.
+//
+// LDS bank conflicts.  ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32 for the
+// upper half): with the 16x16x32 operand map a group mixes columns {0-3, 12-15} of k-group g with columns {4-11} of k-group
+// g + 1, i.e. two DIFFERENT 16-byte chunks of the 128-byte pixel rows.  In the band image (slot q at q * 128, chunk c at
+// c ^ ((q >> 1) & 7)) the 256-byte bank row holds one even and one odd slot, so the group is conflict-free for any pair of
+// chunks iff its two column sets fall on slots of different parity.  Hence the lane -> pixel map is not the identity:
+//     perm16(n) = 2 n (n < 4), 2 n - 7 (4 <= n < 12), 2 n - 16 (n >= 12)
+// columns {0-3, 12-15} take the even pixels of a 16-pixel sub-tile, columns {4-11} the odd ones; eight same-parity slots
+// with one chunk cover the eight chunk positions of their half of the bank row ((q >> 1) & 7 takes every value once).  The
+// weight ring has the same row format, so LDS row j of a 16-row group holds output channel perm16_inv(j) -- applied
+// to the SOURCE row of the weight DMA (computed once per tile), which keeps D's rows in natural channel order.
+//
+// Everything else (contiguous band per 64-channel chunk by LDS-DMA, zero slots by parity for image-edge taps, 2-slot weight
+// ring one tap ahead through a buffer descriptor, persistent workgroups, per-wave staged epilogue, folded projection
+// PCIN) is the 32x32 kernel's design; see the comment above conv3x3_halo_kernel.
+#pragma once
+
+namespace hipac {
+
+template <typename T> struct Elem16;
+template <> struct Elem16<__bf16> {
+  static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem16<_Float16> {
+  static __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// The K step's instruction stream is written out (HIPAC_H16_ASM): hipcc orders every ds_read_b128 right in front of an
+// `s_waitcnt lgkmcnt(0)` (it does not count LDS reads in flight in this loop), which with 16-cycle MFMAs in groups of four
+// leaves ~64 cycles of cover for an LDS round trip, and it renames accumulators between MFMAs (extra live ranges, s_nop
+// padding).  Here: reads HIPAC_H16_AHEAD sub-tiles ahead, counted waits, accumulators updated in place.  asm volatile
+// statements keep their order among themselves; nothing but these statements touches the fragments.
+template <typename T> struct Asm16;
+template <> struct Asm16<__bf16> {
+  static __device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+template <> struct Asm16<_Float16> {
+  static __device__ __forceinline__ void mfma(f32x4& c, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+template <int OFF, typename F>
+__device__ __forceinline__ void lds_read16(F& f, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+  static_assert(N >= 0 && N < 16, "lgkmcnt range");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+
+__host__ __device__ constexpr int perm16(int n) { return n < 4 ? 2 * n : (n < 12 ? 2 * n - 7 : 2 * n - 16); }
+__host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) / 2 : (j < 8 ? j / 2 : j / 2 + 8); }
+
+#ifndef HIPAC_H16_ASM
+#define HIPAC_H16_ASM 1   // 1: the K step as written-out asm statements (see Asm16); 0: builtins, hipcc's schedule
+#endif
+#ifndef HIPAC_H16_SB
+#define HIPAC_H16_SB 1
+#endif
+#ifndef HIPAC_H16_AHEAD
+#define HIPAC_H16_AHEAD (HIPAC_H16_ASM ? 3 : 2)  // activation fragments in flight ahead of the sub-tile whose MFMAs are being issued
+#endif
+
+template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32, int PCIN = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                                const float* __restrict__ bias, const T* __restrict__ resid,
+                                                                void* __restrict__ outp, int M, int n_img, int n_mtiles,
+                                                                const char* __restrict__ zero_page,
+                                                                const T* __restrict__ wgt_p = nullptr) {
+  using E = Elem<T>;
+  using frag = typename E::frag;
+  constexpr int CC = CIN / 64;                      // 64-channel chunks of the K loop
+  constexpr int KTOT = 9 * CIN;
+  constexpr int WM = 2, WN = 2;                     // 4 waves: pixel parts x channel parts
+  constexpr int WPX = BM / WM;                      // pixels per wave
+  constexpr int MT = WPX / 16;                      // 16-pixel sub-tiles per wave (8)
+  constexpr int G32 = WPX / 32;                     // 32-pixel epilogue groups per wave
+  constexpr int WTN = BN / WN, NT = WTN / 16;       // channels per wave, 16-wide tiles per wave (4)
+  constexpr int A_PIECES = halo_band_pieces(W, BM);
+  constexpr int A_BYTES = A_PIECES * 1024;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int WPW = BN / 8 / 4;                   // W pieces per wave per tap
+  constexpr int NTILES_N = COUT / BN;
+  constexpr int PCC = PCIN / 64;                    // projection K steps (0: no folded projection)
+  constexpr int NSTEP = 9 * CC + PCC;
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  static_assert(PCIN % 64 == 0 && (PCIN == 0 || !RESID), "folded projection replaces the residual input");
+  static_assert((BM == 128 || BM == 256) && WTN % 16 == 0 && COUT % BN == 0 && CIN % 64 == 0 && MT <= 8, "tile shape");
+  static_assert((BN / 8) % 4 == 0, "W piece split");
+  static_assert(NSW == 2 || NSW == 3, "weight ring depth");
+  constexpr int SROWW = WTN * 4 + 16;               // staging row: WTN fp32 + pad
+  constexpr int STG_BYTES = 4 * 32 * SROWW;         // 4 waves x [32 px][WTN fp32 + pad] epilogue staging
+  constexpr int S_BYTES = NSW * W_BYTES > STG_BYTES ? NSW * W_BYTES : STG_BYTES;  // ring, aliased by the staging
+  static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
+  // the last sub-tile's taps may read past the tile's own band (tail tiles are not clamped): still inside the band region
+  static_assert(BM + 2 * W + 4 <= A_PIECES * 8, "band slots");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  unsigned char* const Abuf = ring;
+  unsigned char* const Wbuf = ring + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int pn = n16 < 4 ? 2 * n16 : (n16 < 12 ? 2 * n16 - 7 : 2 * n16 - 16);  // perm16(n16)
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const char* in_b = reinterpret_cast<const char*>(in);
+  const char* w_b = reinterpret_cast<const char*>(wgt);
+  const int prow = lane >> 3, dchunk = lane & 7;
+
+  // band of the tile starting at pixel m0_: the contiguous pixel range [m0_ - W - 1, mlast_ + W + 1]
+  auto issue_band_of = [&](int m0_, int cc) {
+    const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
+    const int mstart_ = m0_ - W - 1;
+    const int npx_ = mlast_ - m0_ + 1 + 2 * W + 2;  // band pixels; slots 2..npx+1 (slots 0, 1 = zeros)
+    const int npieces_ = (npx_ + 2 + 7) >> 3;
+    for (int p = wave; p < npieces_; p += 4) {
+      const int q = p * 8 + prow;                // slot
+      const int mm = mstart_ + q - 2;            // flattened pixel held by this slot
+      const bool ok = q >= 2 && q <= npx_ + 1 && mm >= 0 && mm < M;
+      const int schunk = dchunk ^ ((q >> 1) & 7);
+      const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
+    }
+  };
+
+  for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
+  const int xcd = vb & 7, slot = vb >> 3;
+  const int mt = (slot / NTILES_N) * 8 + xcd;
+  const int nt = slot % NTILES_N;
+  if (mt >= n_mtiles) break;  // mt grows with vb on a fixed XCD: nothing valid follows
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
+  const int mstart = m0 - W - 1;
+  if (!first_tile) __builtin_amdgcn_s_barrier();  // the previous tile's staging reads are done: ring is free
+  // weight DMA: LDS row `row` of the tile takes output channel (row & ~15) | perm16_inv(row & 15)
+  int w_off[WPW];
+  int wp_off[PCC > 0 ? WPW : 1];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    const int j = row & 15;
+    const int srow = (row & ~15) | ((j & 1) ? (j + 7) >> 1 : (j < 8 ? j >> 1 : (j >> 1) + 8));
+    w_off[i] = ((n0 + srow) * KTOT + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
+    if constexpr (PCC > 0) wp_off[i] = ((n0 + srow) * PCIN + (dchunk ^ ((row >> 1) & 7)) * 8) * 2;
+  }
+  const rsrc_t w_rsrc = make_rsrc(w_b, COUT * KTOT * 2);
+  const rsrc_t wp_rsrc = make_rsrc(PCC > 0 ? reinterpret_cast<const char*>(wgt_p) : w_b, COUT * (PCC > 0 ? PCIN : KTOT) * 2);
+  auto issue_w = [&](int step, int slot_) {  // weights of step = cc*9 + tap: K offset (tap*CIN + cc*64)
+    if (PCC > 0 && step >= 9 * CC) {  // uniform: a projection step, 64 input channels of the 1x1 matrix
+      const int kofs_bytes = (step - 9 * CC) * 128;
+      static_for<WPW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        buffer_load_lds16(wp_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, wp_off[PCC > 0 ? i : 0], kofs_bytes);
+      });
+      // (an empty statement hipcc cannot merge: without it the two paths' DMA calls are sunk into one block whose descriptor and
+      // offsets are SELECTED -- the offset arrays then live in scratch and every DMA sits in a waterfall loop behind a vmcnt(0))
+      asm volatile("" ::: "memory");
+      return;
+    }
+    const int cc = step / 9, tap = step - cc * 9;
+    const int kofs_bytes = (tap * CIN + cc * 64) * 2;
+    static_for<WPW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
+    });
+  };
+  // folded projection: the block input's pixel (2y, 2x) of every output pixel of the tile, 64 channels of chunk pc, at the
+  // slot the centre tap reads for that output pixel
+  auto issue_gather = [&](int pc) {
+    if constexpr (PCC > 0) {
+      const int npx_ = mlast - m0 + 1;
+      const int first = W + 3, last = first + npx_ - 1;  // slots that hold pixels
+      for (int p = wave + (first >> 3); p <= (last >> 3); p += 4) {
+        const int q = p * 8 + prow;
+        const int mm = m0 + q - first;
+        const bool ok = q >= first && q <= last;
+        const int b = mm / (H * W), rem = mm - b * (H * W), y = rem / W, x = rem - y * W;
+        const int schunk = dchunk ^ ((q >> 1) & 7);
+        const char* src = ok ? reinterpret_cast<const char*>(resid) +
+                                   ((((size_t)b * (2 * H) + 2 * y) * (2 * W) + 2 * x) * PCIN + pc * 64 + schunk * 8) * 2
+                             : zero_page + dchunk * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- consumer side ----
+  // slot of this lane's pixel of sub-tile 0 for the centre tap; sub-tile i is 16 slots on.  Lanes past the end of a tail
+  // tile are NOT clamped: they read slots the band DMA did not fill (inside the band region; MFMA columns are independent
+  // and those columns are never stored).
+  const int mw0 = m0 + wm * WPX + pn;
+  const int q0 = mw0 - mstart + 2;
+  // image-edge flags of the lane's pixel in each sub-tile, 4 bits each: bit 0: x == 0, 1: x == W-1, 2: y == 0, 3: y == H-1
+  unsigned epk = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mw0 + 16 * i;
+    const int b = m / (H * W);
+    const int rem = m - b * (H * W);
+    const int y = rem / W, x = rem - y * W;
+    epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+  }
+  const int ck0 = g << 4;                                                    // k32 step 0: chunk g (step 1: chunk 4 + g)
+  const int rdw0 = (wn * WTN + pn) * 128 + ((g ^ ((pn >> 1) & 7)) << 4);     // weight fragment, k32 step 0, channel tile 0
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // One K step = 64 channels of one tap = two k32 sub-steps of MT x NT MFMAs.  a_addr[i] = byte address of the lane's
+  // fragment of sub-tile i for k32 sub-step 0 (sub-step 1: ^ 64).  `mid` runs once, inside the MFMA stream.
+#if HIPAC_H16_ASM
+  const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)ring;  // LDS byte address of the band region
+  auto k_step = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
+    constexpr int AH = HIPAC_H16_AHEAD;
+    constexpr int NS = 2 * MT;  // (k32 sub-step, pixel sub-tile) pairs in issue order
+    static_assert(AH >= 1 && AH <= 3 && MT >= 2 + NT, "read-ahead schedule");
+    frag wf[2][NT];
+    frag af[AH + 1];
+    const unsigned w0 = lds0 + (unsigned)(wst - ring) + (unsigned)rdw0;
+    const unsigned w1 = w0 ^ 64u;
+    unsigned aa[NS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) aa[i] = lds0 + (unsigned)a_addr[i], aa[MT + i] = aa[i] ^ 64u;
+    // reads in issue order: W0[0..NT), A[0..AH), then per sub-step s: A[s + AH], and W1[s - 1] for s = 1..NT
+    static_for<NT>([&](auto J) { lds_read16<decltype(J)::value * 2048>(wf[0][decltype(J)::value], w0); });
+    static_for<AH>([&](auto S) { lds_read16<0>(af[decltype(S)::value], aa[decltype(S)::value]); });
+    __builtin_amdgcn_s_setprio(1);
+    static_for<NS>([&](auto S) {
+      constexpr int s = decltype(S)::value, kk = s / MT, i = s % MT;
+      if constexpr (s + AH < NS) lds_read16<0>(af[(s + AH) % (AH + 1)], aa[s + AH]);
+      if constexpr (s >= 1 && s <= NT) lds_read16<(s - 1) * 2048>(wf[1][s - 1], w1);
+      // LDS returns in order: wait until only the reads issued AFTER A[s] are outstanding.  Those are A[s+1 .. min(s+AH,
+      // NS-1)] and the W1 reads of sub-steps t in [max(1, s - AH) .. min(s, NT)] (A[s] was issued first thing in sub-step
+      // s - AH, or in the prologue for s < AH).  W0 is older than A[0]; every W1 fragment (issued by sub-step NT) is older than
+      // A[MT] (issued in sub-step MT - AH), the first fragment whose MFMAs need W1.
+      constexpr int a_after = (s + AH < NS ? AH : NS - 1 - s);
+      constexpr int w_lo = (s - AH > 1 ? s - AH : 1), w_hi = (s < NT ? s : NT);
+      constexpr int w_after = w_hi >= w_lo ? w_hi - w_lo + 1 : 0;
+      static_assert(MT - AH >= NT, "W1 fragments are older than the first activation fragment that needs them");
+      wait_lgkmcnt<a_after + w_after>();
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Asm16<T>::mfma(acc[i][j], wf[kk][j], af[s % (AH + 1)]);
+      if constexpr (s == MT / 2) mid();
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+#else
+  auto k_step = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
+    frag wf[2][NT];
+    frag af[HIPAC_H16_AHEAD + 1];
+    constexpr int NS = 2 * MT;  // (k32 sub-step, pixel sub-tile) pairs in issue order
+    auto a_of = [&](int s) -> frag {
+      const int kk = s / MT, i = s % MT;
+      return *reinterpret_cast<const frag*>(Abuf + (kk ? a_addr[i] ^ 64 : a_addr[i]));
+    };
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[0][j] = *reinterpret_cast<const frag*>(wst + j * 2048 + rdw0);
+#pragma unroll
+    for (int s = 0; s < HIPAC_H16_AHEAD; ++s) af[s] = a_of(s);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int kk = s / MT, i = s % MT;
+      if (s + HIPAC_H16_AHEAD < NS) af[(s + HIPAC_H16_AHEAD) % (HIPAC_H16_AHEAD + 1)] = a_of(s + HIPAC_H16_AHEAD);
+      if (kk == 0 && i >= 2 && i < 2 + NT)  // the second sub-step's weight fragments, one per sub-tile
+        wf[1][i - 2] = *reinterpret_cast<const frag*>(wst + (i - 2) * 2048 + (rdw0 ^ 64));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = Elem16<T>::mfma(wf[kk][j], af[s % (HIPAC_H16_AHEAD + 1)], acc[i][j]);
+      if (s == MT / 2) mid();
+#if HIPAC_H16_SB
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads HIPAC_H16_AHEAD sub-tiles ahead of their MFMAs, as written
+#endif
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#endif
+
+  // Epilogue geometry (per WAVE, no workgroup barriers): 32-pixel groups through the wave's private fp32 staging
+  // [32 px][WTN] and out as 16-byte items (8 channels): item = lane + 64k -> pixel item / CPW, channel group lane % CPW.
+  constexpr int CPW = WTN / 8;                      // 8-channel items per pixel (wave's channel half)
+  constexpr int IPT = 32 * CPW / 64;                // items per lane and group
+  static_assert(64 % CPW == 0 && (32 * CPW) % 64 == 0, "epilogue items");
+  const int e_c0 = n0 + wn * WTN + (lane % CPW) * 8;  // first of this lane's 8 output channels
+  const int e_px = lane / CPW;                        // pixel of item k: e_px + k * (64 / CPW)
+  frag rv[2][RESID ? IPT : 1];
+  auto load_resid = [&](auto SUB) {
+    constexpr int i = decltype(SUB)::value;
+    if constexpr (RESID) {
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        int m = m0 + wm * WPX + i * 32 + e_px + k * (64 / CPW);
+        m = m < M ? m : M - 1;  // unconditional load from a valid row (tail rows are never stored)
+        rv[i & 1][k] = *reinterpret_cast<const frag*>(resid + (size_t)m * COUT + e_c0);
+      }
+    }
+  };
+
+  int s = 0;  // K step counter
+  if (first_tile) issue_band_of(m0, 0);
+#pragma unroll
+  for (int pstep = 0; pstep < NSW - 1; ++pstep)
+    if (pstep < NSTEP) issue_w(pstep, pstep);
+  for (int cc = 0; cc < CC; ++cc) {
+    if (cc > 0) {
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
+      issue_band_of(m0, cc);
+    }
+#pragma unroll HIPAC_HALO_TAP_UNROLL
+    for (int tap = 0; tap < 9; ++tap, ++s) {
+      // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
+      if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int toff = (kh - 1) * W + kw - 1;
+      const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+      const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (kh == 2 ? 8u : 0u)) * 0x11111111u;
+      // out-of-image taps read a zero pixel: slot 0 or 1 by the parity of the slot the lane would have read, at the chunk
+      // position its swizzle selects -- the same 16-byte bank group as the in-image address.  (qt + 16 i) has the parity and
+      // the swizzle of qt: one swizzle term per tap.
+      const int qt = q0 + toff;
+      const int x0 = ck0 ^ (((qt >> 1) & 7) << 4);
+      const int a_in = (qt << 7) + x0;
+      const int a_zero = ((qt & 1) << 7) + x0;
+      // (through asm: hipcc would otherwise re-associate (epk & tapmask) & nibble_i into eight pre-masked copies of epk that
+      // live in registers across the whole tile)
+      unsigned em;
+      asm("v_and_b32 %0, %1, %2" : "=v"(em) : "s"(tapmask), "v"(epk));
+      int a_addr[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
+      k_step(wst, a_addr, [&] {
+        // the next step's weight DMA is issued from inside the MFMA stream (its slot was freed by this step's barrier)
+        if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if constexpr (PCC > 0) {
+    // ---- the folded projection: PCC more K steps, centre tap only (no image-edge cases: pixel (2y, 2x) always exists)
+    for (int pc = 0; pc < PCC; ++pc, ++s) {
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
+      issue_gather(pc);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+      const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+      const int a_in = (q0 << 7) + (ck0 ^ (((q0 >> 1) & 7) << 4));
+      int a_addr[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_addr[i] = a_in + 2048 * i;
+      k_step(wst, a_addr, [] {});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+#if HIPAC_H16_ASM
+  // the accumulators were last written by MFMAs hipcc does not know about: the wait states it would have put in front of
+  // their first reader (XDL write -> VALU / LDS read) are spelled out, once per tile
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#endif
+  // the residual of the first 32-pixel group is requested here, not from inside the last K step as in the 32x32 kernel: its
+  // 16 registers do not fit beside the K loop's, and the latency has the barrier, the band prefetch and the staging round
+  // trip of group 0 to hide behind
+  load_resid(std::integral_constant<int, 0>{});
+  const float4 b_lo = *reinterpret_cast<const float4*>(bias + e_c0);
+  const float4 b_hi = *reinterpret_cast<const float4*>(bias + e_c0 + 4);
+  __builtin_amdgcn_s_barrier();  // every wave has left the K loop: band and ring are free
+  {
+    // prefetch the next tile's first band chunk; it lands behind this epilogue
+    const int vn = vb + gridDim.x;
+    const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
+    if (mtn < n_mtiles) issue_band_of(mtn * BM, 0);
+  }
+  unsigned char* const Sl = Wbuf + wave * (32 * SROWW);  // this wave's private staging
+  static_for<G32>([&](auto SUB) {
+    constexpr int i = decltype(SUB)::value;
+    if constexpr (i + 1 < G32) load_resid(std::integral_constant<int, i + 1>{});
+    // accumulators -> fp32 rows: sub-tiles 2i (staging pixels 0-15) and 2i+1 (16-31); a lane holds channels 4g .. 4g+3 of
+    // every 16-wide tile of pixel pn (LDS operations of one wave complete in order: no barrier)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<f32x4*>(Sl + (hh * 16 + pn) * SROWW + (j * 16 + 4 * g) * 4) = acc[2 * i + hh][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const int px = e_px + k * (64 / CPW);
+      const int m = m0 + wm * WPX + i * 32 + px;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Sl + px * SROWW + (lane % CPW) * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(Sl + px * SROWW + (lane % CPW) * 32 + 16);
+      if (m < M) {
+        float v[8] = {lo[0] + b_lo.x, lo[1] + b_lo.y, lo[2] + b_lo.z, lo[3] + b_lo.w,
+                      hi[0] + b_hi.x, hi[1] + b_hi.y, hi[2] + b_hi.z, hi[3] + b_hi.w};
+        const size_t o = (size_t)m * COUT + e_c0;
+        if constexpr (RESID) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[i & 1][k][e];
+        }
+        if constexpr (RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (OUTF32) {
+          float* op = reinterpret_cast<float*>(outp) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          frag ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (T)v[e];
+          *reinterpret_cast<frag*>(reinterpret_cast<T*>(outp) + o) = ov;
+        }
+      }
+    }
+    // the next group overwrites the staging rows: this wave's reads above must have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+  }  // persistent tile loop
+}
+
+}  // namespace hipac
