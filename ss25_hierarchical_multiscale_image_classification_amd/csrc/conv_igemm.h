@@ -902,6 +902,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
   };
 
   HALO_STAMP(t_start);
+#ifdef HIPAC_HALO_STAMPS
+  unsigned long long t_first = 0;
+#endif
   int s = 0;  // K step counter
   if constexpr (DBLW) {
     // ---- double weight steps (see the template note): step = (chunk c, phase, tap), phase 0 = hi plane x [Whi | Wlo]
@@ -990,9 +993,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
 #pragma unroll
   for (int pstep = 0; pstep < NSW - 1; ++pstep)
     if (pstep < NSTEP) issue_w(pstep, pstep);
-#ifdef HIPAC_HALO_STAMPS
-  unsigned long long t_first = 0;
-#endif
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0 && (!SPLIT || cc % 3 != 1)) {  // (SPLIT: chunk 3c + 1 multiplies the band of 3c by the low weight halves)
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band

@@ -66,6 +66,16 @@ __device__ __forceinline__ void lds_read16(F& f, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// rows = 16 lanes: a.row1 <-> b.row0, a.row3 <-> b.row2 (tools/permswap16_probe.hip)
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#else
+__device__ inline void permlane16_swap(unsigned&, unsigned&) {}
+#endif
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
   static_assert(N >= 0 && N < 16, "lgkmcnt range");
@@ -77,6 +87,13 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
 
 #ifndef HIPAC_H16_ASM
 #define HIPAC_H16_ASM 1   // 1: the K step as written-out asm statements (see Asm16); 0: builtins, hipcc's schedule
+#endif
+#ifndef HIPAC_H16_DIRECT
+#define HIPAC_H16_DIRECT 1  // 1: epilogue straight from the accumulators (v_permlane16_swap pairs 16-lane rows into 16-byte
+                            // items), the next tile's band AND first weight tiles prefetched behind it; 0: staged through LDS
+#endif
+#ifndef HIPAC_H16_ABL
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -136,22 +153,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   const char* w_b = reinterpret_cast<const char*>(wgt);
   const int prow = lane >> 3, dchunk = lane & 7;
 
-  // band of the tile starting at pixel m0_: the contiguous pixel range [m0_ - W - 1, mlast_ + W + 1]
+  // band of the tile starting at pixel m0_: the contiguous pixel range [m0_ - W - 1, mlast_ + W + 1], slot q = pixel
+  // m0_ - W - 3 + q (slots 0, 1 = zeros).  Through a buffer descriptor over the activation map: pixels before the first image
+  // (negative offsets wrap to huge unsigned ones) and after the last one read as zeros by the range check, slots 0 and 1 are
+  // sent out of range explicitly, and a lane's offset inside a piece does not depend on the piece -- a wave's pieces
+  // p = wave, wave + 4, ... all have p's parity, so the swizzle term (q >> 1) & 7 = (4 p + (prow >> 1)) & 7 is a per-lane
+  // constant: one add per piece.  (Slots past the band's end receive whatever pixels follow; no stored result reads them.)
+  const rsrc_t a_rsrc = make_rsrc(in_b, M * CIN * 2);
+  const int a_lane = (prow * CIN + (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 8) * 2;
   auto issue_band_of = [&](int m0_, int cc) {
     const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
-    const int mstart_ = m0_ - W - 1;
-    const int npx_ = mlast_ - m0_ + 1 + 2 * W + 2;  // band pixels; slots 2..npx+1 (slots 0, 1 = zeros)
-    const int npieces_ = (npx_ + 2 + 7) >> 3;
+    const int npieces_ = (mlast_ - m0_ + 1 + 2 * W + 2 + 2 + 7) >> 3;
+    const int base = ((m0_ - W - 3) * CIN + cc * 64) * 2;  // byte offset of slot 0's pixel (may be negative)
     for (int p = wave; p < npieces_; p += 4) {
-      const int q = p * 8 + prow;                // slot
-      const int mm = mstart_ + q - 2;            // flattened pixel held by this slot
-      const bool ok = q >= 2 && q <= npx_ + 1 && mm >= 0 && mm < M;
-      const int schunk = dchunk ^ ((q >> 1) & 7);
-      const char* src = ok ? in_b + ((size_t)mm * CIN + cc * 64 + schunk * 8) * 2 : zero_page + dchunk * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Abuf + p * 1024), 16, 0, 0);
+      int off = a_lane + base + p * (8 * CIN * 2);
+      if (p == 0 && prow < 2) off = (int)0x80000000;
+      buffer_load_lds16(a_rsrc, Abuf + p * 1024, off, 0);
     }
   };
 
+  // DIRECT: the next tile's band and first weights are requested BEFORE the epilogue's stores, and vector-memory operations
+  // retire in order: at the next tile's first step it is enough to wait until only those stores are outstanding -- if every
+  // one of them was issued, i.e. the tile was full (a store whose lanes are all past M may be branched around)
+  constexpr int N_EPI_STORES = MT * (OUTF32 ? NT : NT / 2);
+  bool prev_full = false;
   for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
   const int xcd = vb & 7, slot = vb >> 3;
   const int mt = (slot / NTILES_N) * 8 + xcd;
@@ -160,7 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   const int m0 = mt * BM, n0 = nt * BN;
   const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
   const int mstart = m0 - W - 1;
-  if (!first_tile) __builtin_amdgcn_s_barrier();  // the previous tile's staging reads are done: ring is free
+  constexpr bool DIRECT = HIPAC_H16_DIRECT != 0;
+  HALO_STAMP(t_start);
+  if (!DIRECT && !first_tile) __builtin_amdgcn_s_barrier();  // the previous tile's staging reads are done: ring is free
   // weight DMA: LDS row `row` of the tile takes output channel (row & ~15) | perm16_inv(row & 15)
   int w_off[WPW];
   int wp_off[PCC > 0 ? WPW : 1];
@@ -221,14 +248,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   const int q0 = mw0 - mstart + 2;
   // image-edge flags of the lane's pixel in each sub-tile, 4 bits each: bit 0: x == 0, 1: x == W-1, 2: y == 0, 3: y == H-1
   unsigned epk = 0;
+  {
+    // (x, y) of sub-tile 0's pixel by division, the others by stepping 16 pixels on: 16 = (16 / W) rows + (16 % W) columns
+    const int rem = mw0 % (H * W);
+    int y = rem / W, x = rem - y * W;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = mw0 + 16 * i;
-    const int b = m / (H * W);
-    const int rem = m - b * (H * W);
-    const int y = rem / W, x = rem - y * W;
-    epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+    for (int i = 0; i < MT; ++i) {
+      epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+      x += 16 % W, y += 16 / W;
+      if (x >= W) x -= W, y += 1;
+      if (y >= H) y -= H;
+    }
   }
+  HALO_STAMP(t_setup);
   const int ck0 = g << 4;                                                    // k32 step 0: chunk g (step 1: chunk 4 + g)
   const int rdw0 = (wn * WTN + pn) * 128 + ((g ^ ((pn >> 1) & 7)) << 4);     // weight fragment, k32 step 0, channel tile 0
 
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       constexpr int w_lo = (s - AH > 1 ? s - AH : 1), w_hi = (s < NT ? s : NT);
       constexpr int w_after = w_hi >= w_lo ? w_hi - w_lo + 1 : 0;
       static_assert(MT - AH >= NT, "W1 fragments are older than the first activation fragment that needs them");
-      wait_lgkmcnt<a_after + w_after>();
+      if constexpr (!(HIPAC_H16_ABL & 4)) wait_lgkmcnt<a_after + w_after>();
 #pragma unroll
       for (int j = 0; j < NT; ++j) Asm16<T>::mfma(acc[i][j], wf[kk][j], af[s % (AH + 1)]);
       if constexpr (s == MT / 2) mid();
@@ -327,11 +359,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     }
   };
 
+#ifdef HIPAC_HALO_STAMPS
+  unsigned long long t_first = 0;
+#endif
   int s = 0;  // K step counter
   if (first_tile) issue_band_of(m0, 0);
+  if (!DIRECT || first_tile) {  // (DIRECT: the previous tile's epilogue has requested them)
 #pragma unroll
-  for (int pstep = 0; pstep < NSW - 1; ++pstep)
-    if (pstep < NSTEP) issue_w(pstep, pstep);
+    for (int pstep = 0; pstep < NSW - 1; ++pstep)
+      if (pstep < NSTEP) issue_w(pstep, pstep);
+  }
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0) {
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
@@ -341,8 +378,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     for (int tap = 0; tap < 9; ++tap, ++s) {
       // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
       if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
+      else if (DIRECT && s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the epilogue's stores
       else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      if (!(HIPAC_H16_ABL & 1) || tap == 0) __builtin_amdgcn_s_barrier();
+#ifdef HIPAC_HALO_STAMPS
+      if (s == 0) {
+        t_first = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      }
+#endif
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
@@ -363,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
       k_step(wst, a_addr, [&] {
         // the next step's weight DMA is issued from inside the MFMA stream (its slot was freed by this step's barrier)
-        if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+        if (!(HIPAC_H16_ABL & 2) && s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -387,11 +431,130 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
+  HALO_STAMP(t_loop);
 #if HIPAC_H16_ASM
   // the accumulators were last written by MFMAs hipcc does not know about: the wait states it would have put in front of
   // their first reader (XDL write -> VALU / LDS read) are spelled out, once per tile
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
 #endif
+  if constexpr (DIRECT) {
+    // ---- direct epilogue: no LDS.  Lane (n, g) holds channels 16 j + 4 g .. + 3 of pixel perm16(n) of every sub-tile: two
+    // packed dwords per 16-wide tile j.  v_permlane16_swap on the dwords of tiles (2 jp, 2 jp + 1) leaves every lane with
+    // 16 contiguous bytes -- row g of the wave stores channels 32 jp + 16 (g & 1) + 8 (g >> 1) .. + 7 -- so one store
+    // instruction writes 64 contiguous bytes per pixel (the 32x32 form of this idea gave 32-byte runs and lost to the
+    // staged form).  The residual arrives in the stored layout and is un-paired by the same swap (an involution).
+    float4 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + n0 + wn * WTN + 16 * j + 4 * g);
+    const int c_lane = n0 + wn * WTN + 16 * (g & 1) + 8 * (g >> 1);  // + 32 jp: first of the 8 channels this lane stores
+    // ALL of the tile's residual loads are requested up front (the K loop's fragment registers are free now): vector-memory
+    // operations retire in order, so a load requested later would queue behind the next tile's band and weight DMA below
+    u32x4 rq[MT][RESID && !OUTF32 ? NT / 2 : 1];
+    u32x2 rq32[MT][RESID && OUTF32 ? NT : 1];
+    auto load_resid_d = [&](auto SUB) {
+      constexpr int i = decltype(SUB)::value;
+      if constexpr (RESID) {
+        int m = mw0 + 16 * i;
+        m = m < M ? m : M - 1;  // unconditional load from a valid row (tail rows are never stored)
+        if constexpr (OUTF32) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            rq32[i][j] = *reinterpret_cast<const u32x2*>(resid + (size_t)m * COUT + n0 + wn * WTN + 16 * j + 4 * g);
+        } else {
+#pragma unroll
+          for (int jp = 0; jp < NT / 2; ++jp)
+            rq[i][jp] = *reinterpret_cast<const u32x4*>(resid + (size_t)m * COUT + c_lane + 32 * jp);
+        }
+      }
+    };
+    static_for<MT>([&](auto SUB) { load_resid_d(SUB); });
+    __builtin_amdgcn_s_barrier();  // every wave has left the K loop: band and ring are free
+    HALO_STAMP(t_bar);
+    {
+      // the next tile's first band chunk and first weight tile(s) land behind this epilogue
+      const int vn = vb + gridDim.x;
+      const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
+      if (mtn < n_mtiles) {
+        issue_band_of(mtn * BM, 0);
+        const int dn = (((vn >> 3) % NTILES_N) * BN - n0) * KTOT * 2;  // the next tile's weight rows relative to this one's
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) w_off[i] += dn;
+#pragma unroll
+        for (int pstep = 0; pstep < NSW - 1; ++pstep)
+          if (pstep < 9 * CC) issue_w(pstep, pstep);
+      }
+    }
+    HALO_STAMP(t_pref);
+    static_for<MT>([&](auto SUB) {
+      constexpr int i = decltype(SUB)::value;
+      const int m = mw0 + 16 * i;
+      if constexpr (OUTF32) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+          if constexpr (RESID) {
+            const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, rq32[i][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          }
+          if constexpr (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (m < M)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * COUT + n0 + wn * WTN + 16 * j + 4 * g) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int jp = 0; jp < NT / 2; ++jp) {
+          unsigned R[4] = {0u, 0u, 0u, 0u};
+          if constexpr (RESID) {
+            R[0] = rq[i][jp][0], R[1] = rq[i][jp][1], R[2] = rq[i][jp][2], R[3] = rq[i][jp][3];
+            permlane16_swap(R[0], R[2]);  // -> (R[0], R[1]) = this lane's 4 channels of tile 2 jp, (R[2], R[3]) = of tile 2 jp + 1
+            permlane16_swap(R[1], R[3]);
+          }
+          unsigned P[2][2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * jp + jj;
+            float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+            if constexpr (RESID) {
+              const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, u32x2{R[2 * jj], R[2 * jj + 1]});
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            }
+            if constexpr (RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            P[jj][0] = PackPair<T>::pack_rn(v[0], v[1]);
+            P[jj][1] = PackPair<T>::pack_rn(v[2], v[3]);
+          }
+          permlane16_swap(P[0][0], P[1][0]);
+          permlane16_swap(P[0][1], P[1][1]);
+          if (m < M)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + c_lane + 32 * jp) =
+                u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
+        }
+      }
+    });
+#ifdef HIPAC_HALO_STAMPS
+    HALO_STAMP(t_end);
+    if (tid == 0) {
+      atomicAdd(&g_halo_stamps[0], t_first - t_start);
+      atomicAdd(&g_halo_stamps[1], t_loop - t_first);
+      atomicAdd(&g_halo_stamps[2], t_end - t_loop);
+      atomicAdd(&g_halo_stamps[3], 1ull);
+      atomicAdd(&g_halo_stamps[4], t_bar - t_loop);
+      atomicAdd(&g_halo_stamps[5], t_pref - t_bar);
+      atomicAdd(&g_halo_stamps[6], t_end - t_pref);
+      atomicAdd(&g_halo_stamps[7], t_setup - t_start);
+    }
+#endif
+    prev_full = (m0 + BM <= M);
+    continue;  // next tile
+  }
   // the residual of the first 32-pixel group is requested here, not from inside the last K step as in the 32x32 kernel: its
   // 16 registers do not fit beside the K loop's, and the latency has the barrier, the band prefetch and the staging round
   // trip of group 0 to hide behind
@@ -399,12 +562,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   const float4 b_lo = *reinterpret_cast<const float4*>(bias + e_c0);
   const float4 b_hi = *reinterpret_cast<const float4*>(bias + e_c0 + 4);
   __builtin_amdgcn_s_barrier();  // every wave has left the K loop: band and ring are free
+  HALO_STAMP(t_bar);
   {
     // prefetch the next tile's first band chunk; it lands behind this epilogue
     const int vn = vb + gridDim.x;
     const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
     if (mtn < n_mtiles) issue_band_of(mtn * BM, 0);
   }
+  HALO_STAMP(t_pref);
   unsigned char* const Sl = Wbuf + wave * (32 * SROWW);  // this wave's private staging
   static_for<G32>([&](auto SUB) {
     constexpr int i = decltype(SUB)::value;
@@ -450,6 +615,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     // the next group overwrites the staging rows: this wave's reads above must have returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
+#ifdef HIPAC_HALO_STAMPS
+  HALO_STAMP(t_end);
+  if (tid == 0) {
+    atomicAdd(&g_halo_stamps[0], t_first - t_start);  // prologue: band + first weight tile in flight
+    atomicAdd(&g_halo_stamps[1], t_loop - t_first);   // K loop
+    atomicAdd(&g_halo_stamps[2], t_end - t_loop);     // epilogue (all of it)
+    atomicAdd(&g_halo_stamps[3], 1ull);
+    atomicAdd(&g_halo_stamps[4], t_bar - t_loop);     // ... of which: waiting for the other waves to leave the K loop
+    atomicAdd(&g_halo_stamps[5], t_pref - t_bar);     // ... issuing the next tile's band
+    atomicAdd(&g_halo_stamps[6], t_end - t_pref);     // ... the staged groups
+  }
+#endif
   }  // persistent tile loop
 }
 

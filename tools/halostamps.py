@@ -30,7 +30,9 @@ for i, name in enumerate(names):
     n = max(1, buf[3])
     tot = max(1, buf[0] + buf[1] + buf[2])
     print(f"{name}: workgroups {buf[3]}  per workgroup (s_memtime = shader cycles): prologue {buf[0]/n:.0f}  "
-          f"K loop {buf[1]/n:.0f}  epilogue {buf[2]/n:.0f}   shares {buf[0]/tot:.2f} / {buf[1]/tot:.2f} / {buf[2]/tot:.2f}")
+          f"K loop {buf[1]/n:.0f}  epilogue {buf[2]/n:.0f}   shares {buf[0]/tot:.2f} / {buf[1]/tot:.2f} / {buf[2]/tot:.2f}"
+          + (f"   epilogue = barrier {buf[4]/n:.0f} + next band issue {buf[5]/n:.0f} + staged groups {buf[6]/n:.0f}" if buf[6] else "")
+          + (f"   prologue = setup {buf[7]/n:.0f} + wait for DMA / other waves {(buf[0]-buf[7])/n:.0f}" if buf[7] else ""))
 
 for i, name in enumerate(names):
     if not name.startswith("l1"):
