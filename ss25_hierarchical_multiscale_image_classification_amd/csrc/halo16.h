@@ -93,7 +93,7 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
                             // items), the next tile's band AND first weight tiles prefetched behind it; 0: staged through LDS
 #endif
 #ifndef HIPAC_H16_ABL
-#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
       if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
       else if (DIRECT && s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the epilogue's stores
-      else wait_vmcnt<0>();
+      else if (!(HIPAC_H16_ABL & 8) || tap == 0) wait_vmcnt<0>();  // (ablation 8: weight tiles are not waited for)
       if (!(HIPAC_H16_ABL & 1) || tap == 0) __builtin_amdgcn_s_barrier();
 #ifdef HIPAC_HALO_STAMPS
       if (s == 0) {
