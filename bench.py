@@ -670,9 +670,14 @@ def main(argv=None):
     abandon = bool(rec.pop("_abandon_process_group", False))
     if rank == 0:
         print(json.dumps(rec), flush=True)
-    if abandon:  # a collective is still stuck in a worker thread: the line is out, do not wait for the group
+    if abandon:
+        # a collective is still stuck in a worker thread: the line is out (with its "error" object), the group is not waited
+        # for -- and the process reports the fault: a hung collective is a failure the launcher and the driver must see
+        # (launch_ranks names the rank and terminates its siblings), never a silent rc 0
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.write(f"[bench] rank {rank}: a collective did not return within --simclr_timeout; exiting with code 3\n")
+        sys.stderr.flush()
+        os._exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

@@ -29,8 +29,11 @@ Pinning status (see DESIGN.md "Oracle"):
                 parameters + 1,026 fc; output shapes) and on agreement
                 between an nn.Module restatement and the functional one.
   * NT-Xent   - restated from src/models/simclr.py:31-54 (pure torch); that
-                file cannot be imported (top-level torchvision import), so
-                PARITY UNPINNED beyond closed-form known answers.
+                file cannot be imported whole (top-level torchvision import),
+                but its nt_xent_loss definition compiles on its own:
+                tests/golden/make_golden_ntxent.py ran the reference's OWN
+                function in the build container and stored inputs, values and
+                gradients (tests/golden/ntxent_golden.npz) -- PINNED on those.
   * dataset   - src/datasets/patch_dataset.py imports by file location in the
                 build container; tests/golden/patch_dataset_ref.json was
                 generated from it (script committed beside it).

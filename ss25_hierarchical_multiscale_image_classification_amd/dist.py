@@ -65,19 +65,28 @@ def shard_columns(n_cols: int, rank: int, world: int) -> Tuple[int, int]:
     return c0, c0 + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+def exchange_counts(n: int, device, group=None) -> List[int]:
+    """Every rank's row count (one small all-gather + one host synchronisation)."""
+    world = dist.get_world_size(group)
+    if torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo":
+        device = "cpu"
+    t = torch.tensor([n], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(counts, t, group=group)
+    return [int(c.item()) for c in counts]
+
+
+def all_gather_rows(t: torch.Tensor, group=None, counts: Optional[List[int]] = None) -> torch.Tensor:
     """All-gather-v along dim 0 (ranks may hold different row counts): one int64 count
-    exchange, then one all-gather on a max-padded buffer, trimmed and concatenated in
-    rank order."""
+    exchange (skipped when the caller already holds ``counts``), then one all-gather on a max-padded
+    buffer, trimmed and concatenated in rank order."""
     if not active(group):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":  # gloo has no CUDA all_gather: stage through the host
-        return all_gather_rows(t.cpu(), group).to(t.device)
+        return all_gather_rows(t.cpu(), group, counts).to(t.device)
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        counts = exchange_counts(t.shape[0], t.device, group)
     n_max = max(counts)
     if n_max == 0:
         return t
@@ -102,9 +111,13 @@ def all_gather_equal(t: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def gather_results(feats: torch.Tensor, logits: Optional[torch.Tensor], meta: torch.Tensor, group=None):
-    """Collect every rank's per-patch rows on every rank (rank-major order)."""
-    return (all_gather_rows(feats, group), all_gather_rows(logits, group) if logits is not None else None,
-            all_gather_rows(meta, group))
+    """Collect every rank's per-patch rows on every rank (rank-major order): ONE count exchange for the three
+    tensors (they have the same rows), then one padded all-gather each."""
+    if not active(group):
+        return feats, logits, meta
+    counts = exchange_counts(feats.shape[0], feats.device, group)
+    return (all_gather_rows(feats, group, counts), all_gather_rows(logits, group, counts) if logits is not None else None,
+            all_gather_rows(meta, group, counts))
 
 
 def rank_world() -> Tuple[int, int]:
@@ -199,9 +212,11 @@ class RankBatchSampler(torch.utils.data.Sampler):
                 yield idx[self.rank * per:(self.rank + 1) * per]
 
     def __iter__(self):
-        it = self._batches()
+        # the permutation of THIS epoch is drawn now (a generator would read self.epoch only at its first next(), i.e.
+        # after the increment below): set_epoch(e) yields epoch e's order, as the device loaders do
+        batches = list(self._batches())
         self.epoch += 1  # a new permutation per pass, the same one on every rank
-        return it
+        return iter(batches)
 
     def __len__(self):
         full, rem = divmod(self.n, self.batch_size)

@@ -122,7 +122,10 @@ def list_slides(args):
             slide = DeviceSlide.from_tiff(path, name=stem)
         xml = os.path.join(ann_dir, stem + ".xml")
         if os.path.exists(xml):
-            slide.polygons = parse_annotation_xml(xml)
+            try:  # a bad annotation file costs the slide its tumour labels, not the run (src/main.py:670-675)
+                slide.polygons = parse_annotation_xml(xml)
+            except Exception as e:
+                print(f"[WARNING] Failed to parse XML for {os.path.basename(path)}: {e}")
         return slide
 
     for file in sorted(os.listdir(img_dir)):
@@ -132,13 +135,27 @@ def list_slides(args):
     return out
 
 
+def try_open(name: str, make):
+    """The slide, or None after ``[ERROR] Could not open ...`` -- the reference opens every slide under try / except ...
+    continue (src/main.py:649-653): one unreadable file costs that slide, not the run (under --world_size N: not the
+    other N - 1 ranks either; the owning rank contributes zero rows for it)."""
+    try:
+        return make()
+    except Exception as e:  # noqa: BLE001 -- whatever the reader raises for a truncated / foreign file
+        print(f"[ERROR] Could not open {name}: {type(e).__name__}: {e}", flush=True)
+        return None
+
+
 def open_slides(args, rank: int = 0, world: int = 1):
-    """Yield (index, DeviceSlide) of the slides this rank owns (slide i -> rank i mod world)."""
+    """Yield (index, DeviceSlide) of the slides this rank owns (slide i -> rank i mod world); slides that
+    cannot be opened are reported and skipped."""
     from .dist import shard_units
 
     slides = list_slides(args)
     for i in shard_units(len(slides), rank, world):
-        yield i, slides[i][1]()
+        slide = try_open(slides[i][0], slides[i][1])
+        if slide is not None:
+            yield i, slide
 
 
 def cmd_patch(args):
@@ -208,7 +225,11 @@ def cmd_extract_features(args):
             return 1
 
         def score(i):
-            f, _, _, meta = score_slide(slides[i][1](), net, levels=(level,), batch_windows=512, stride=args.stride,
+            slide = try_open(slides[i][0], slides[i][1])
+            if slide is None:  # zero rows for this unit; the exchange and the other slides go on
+                dev = torch.device("cuda", torch.cuda.current_device())
+                return torch.zeros((0, 512), dtype=torch.float32, device=dev), None, torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            f, _, _, meta = score_slide(slide, net, levels=(level,), batch_windows=512, stride=args.stride,
                                         want_logits=False)
             return f, None, meta
 
@@ -230,7 +251,8 @@ def cmd_train(args, strategy: Optional[str]):
     level = int(args.patch_level) if args.patch_level != "all" else 3
     patch_dir = os.path.join(data_root(args), "patches", f"level_{level}")
     if args.from_slides:
-        slides = [make() for _, make in list_slides(args)]  # every rank holds every slide: batches are shared out, not slides
+        # every rank holds every slide: batches are shared out, not slides (an unreadable file is skipped on every rank alike)
+        slides = [s for s in (try_open(name, make) for name, make in list_slides(args)) if s is not None]
         train_resnet_classifier(None, strategy=strategy, epochs=args.epochs, batch_size=args.batch_size, precision=args.precision,
                                 simclr_epochs=args.simclr_epochs, max_steps=args.max_steps, train_precision=args.train_precision,
                                 simclr_precision=args.simclr_precision, slides=slides, level=level)
@@ -287,12 +309,22 @@ def main(argv=None) -> int:
             torch.distributed.destroy_process_group()
 
 
+def _rendezvous():
+    """--world_size N: the commands of one invocation run back to back on every rank, and the next one lists what the
+    previous one wrote (the PNG tree, the feature files): nobody moves on before everybody is done.  Also keeps the ranks
+    that sit out a rank-0-only phase (the PNG branch of --extract_features) out of the next command's collectives."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.barrier()
+
+
 def _dispatch(args) -> int:
     rc = 0
     if args.patch:
         cmd_patch(args)
+        _rendezvous()
     if args.extract_features:
         rc = cmd_extract_features(args) or rc
+        _rendezvous()
     if args.train:
         rc = cmd_train(args, None) or rc
     if args.train_strategy:

@@ -206,6 +206,9 @@ def train_resnet_classifier(patch_dir: str, strategy: Optional[str] = None, epoc
     history, steps = [], 0
     for epoch in range(epochs):
         total, correct, seen = 0.0, 0, 0
+        # a fresh GradScaler per epoch, as both reference loops construct theirs INSIDE the epoch loop (src/main.py:498, :577):
+        # scale and growth tracker restart at 65536 / 0, so the first steps of an epoch skip on overflow as the reference's do
+        trainer.scaler = type(trainer.scaler)(enabled=trainer.scaler.enabled)
         for imgs, labels, _ in train_loader:
             loss, logits = trainer.step(imgs.to(dev, torch.float32).contiguous(), labels)
             total += float(loss)  # N > 1: already the loss of the global batch

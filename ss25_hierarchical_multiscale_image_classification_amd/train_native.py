@@ -416,6 +416,9 @@ class NativeClassifierTrainer:
         L, r0 = _all_gather_rows(logits)
         Y, _ = _all_gather_rows(labels)
         dL = torch.empty_like(L)
+        need = 2 + 8 * ((int(L.shape[0]) + 255) // 256)  # the kernel's scratch: 2 + 8 floats per 256 rows of the GLOBAL batch
+        if self._scratch.numel() < need:  # grow-only (the ABI carries no scratch size: the binding owns this contract)
+            self._scratch = torch.zeros(need, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             capi._check(capi.load_library().hipac_cross_entropy_fwd_bwd(
                 L.data_ptr(), Y.data_ptr(), capi._ptr(self.class_weights), L.shape[0], L.shape[1],

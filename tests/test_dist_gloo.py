@@ -121,3 +121,47 @@ def test_equal_shard_gather_is_rank_major():
     exp_lab = np.concatenate([np.arange(3) + 10 * r for r in range(2)])
     for l, lab in outs:
         assert np.array_equal(l, exp_l) and np.array_equal(lab, exp_lab)
+
+
+def _count_job(rank, world):
+    # gather_results: ONE count exchange for features / logits / meta (they share their row counts), then one padded
+    # all-gather per tensor -- four collectives, not six
+    units = _units(5)
+    mine = hdist.shard_units(5, rank, world)
+    cat = lambda i: torch.cat([units[u][i] for u in mine]) if mine else units[0][i][:0]
+    calls = []
+    real = dist.all_gather
+
+    def counting(out, t, group=None):
+        calls.append(tuple(t.shape))
+        return real(out, t, group=group)
+
+    dist.all_gather = counting
+    try:
+        hdist.gather_results(cat(0), cat(1), cat(2))
+    finally:
+        dist.all_gather = real
+    return calls
+
+
+def test_gather_results_exchanges_counts_once():
+    for calls in _run(2, _count_job):
+        assert len(calls) == 4 and calls[0] == (1,) and all(len(c) == 2 for c in calls[1:]), calls
+
+
+def test_rank_batch_sampler_epoch_convention():
+    # set_epoch(e) yields epoch e's permutation (seed + e), the pass after it epoch e + 1's: the convention of the device loaders
+    def perm(e):
+        g = torch.Generator()
+        g.manual_seed(7 + e)
+        return torch.randperm(10, generator=g).tolist()
+
+    s = hdist.RankBatchSampler(10, 5, rank=0, world=1, shuffle=True, seed=7)
+    s.set_epoch(3)
+    assert [i for b in s for i in b] == perm(3)
+    assert [i for b in s for i in b] == perm(4)
+    # two ranks draw the same permutation and take complementary halves of every batch
+    a = hdist.RankBatchSampler(10, 4, rank=0, world=2, shuffle=True, seed=1)
+    b = hdist.RankBatchSampler(10, 4, rank=1, world=2, shuffle=True, seed=1)
+    for ba, bb in zip(a, b):
+        assert len(ba) == len(bb) and not set(ba) & set(bb)
