@@ -72,7 +72,8 @@ KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block_c64_kern
 
 
 def kernel_of(op: str) -> str:
-    return KERNEL_OF_OP.get(op) or KERNEL_OF_OP.get(op[:2]) or "conv3x3_halo_kernel"
+    # the stride-1 3x3 convs of layers 2-4: the halo kernel on v_mfma_f32_16x16x32 (csrc/halo16.h) for bf16 / fp16
+    return KERNEL_OF_OP.get(op) or KERNEL_OF_OP.get(op[:2]) or "conv3x3_halo16_kernel"
 
 
 def host_threads() -> int:
@@ -264,9 +265,21 @@ def scan_slide_timed(net, slide, args, world, steps, warmup, dev):
             torch.cuda.synchronize()
             marks.append(time.perf_counter())
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0  # this rank's own scans + exchanges, before it waits for the others
+    scan_slide_timed.rank_stats = None
     if world > 1:
         torch.distributed.barrier()
     dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
+    if world > 1:
+        # load balance of one-slide-per-rank: every rank's kept windows and own time (the only thing between this
+        # partitioning and linear scaling is the spread of these)
+        t = torch.tensor([dt_local / steps, float(n_kept)], dtype=torch.float64,
+                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(lst, t)
+        secs = [float(x[0]) for x in lst]
+        scan_slide_timed.rank_stats = {"kept_per_rank": [int(x[1]) for x in lst], "rank_s_per_slide": [round(v, 5) for v in secs],
+                                       "rank_s_max": max(secs), "rank_s_min": min(secs)}
     scan_slide_timed.last_scans = [b - a for a, b in zip([t0] + marks[:-1], marks)]
     return dt / steps, n_all, n_kept
 
@@ -287,6 +300,10 @@ def wsi_object(net, args, rank, world, dev, sides):
                    "windows": n_all, "kept": n_kept, "n_gpus": world, "slides": world,
                    "kept_patches_per_s": world * n_kept / s_per if world == 1 else None,
                    "unique_source_GBps": world * sum(w * h * 3 for (w, h) in slide.level_dimensions) / s_per / 1e9}
+            if getattr(scan_slide_timed, "rank_stats", None):
+                rec.update(scan_slide_timed.rank_stats)
+                rec["kept_all_ranks"] = sum(rec["kept_per_rank"])
+                rec["kept_patches_per_s"] = rec["kept_all_ranks"] / s_per
             if rank == 0:
                 rec["roofline"] = planes_roofline(slide, side)
             out[key] = rec
@@ -350,9 +367,10 @@ def run_resnet(args, rank, world, dev):
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_DENSE_TFLOPS,
                            "traffic": traffic, "launch_ms": dom["ms"], "flops_per_launch": dom["flops_per_launch"],
                            "images_per_launch": dom["images"]}
-        rec["per_op"] = [{"op": o["op"], "kernel": kernel_of(o["op"]) if o["tflops"] else None, "images": o["images"],
-                          "ms": round(o["ms"], 4), "tflops": None if o["tflops"] is None else round(o["tflops"], 1),
-                          "frac": None if o["tflops"] is None else round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3)} for o in ops]
+        # (the op slots a fused kernel leaves empty are not work: their "time" is the event pair's own overhead -- left out)
+        rec["per_op"] = [{"op": o["op"], "kernel": kernel_of(o["op"]), "images": o["images"],
+                          "ms": round(o["ms"], 4), "tflops": round(o["tflops"], 1),
+                          "frac": round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3)} for o in ops if o["tflops"]]
         if traffic is not None:
             tj = json.load(open(tpath))
             rec["roofline"]["traffic_source"] = ("profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), "
@@ -569,7 +587,7 @@ def run_wsi(args, rank, world, dev):
     slide = extract.DeviceSlide.synthetic(side, side, seed=10 + rank, with_polygons=True)
     s_per, n_all, n_kept = scan_slide_timed(net, slide, args, world, args.steps, args.warmup, dev)
     unique_bytes = sum(w * h * 3 for (w, h) in slide.level_dimensions)
-    extra = {}
+    extra = dict(getattr(scan_slide_timed, "rank_stats", None) or {})
     if rank == 0:
         extra["roofline"] = planes_roofline(slide, side)
         if world == 1 and not args.no_cpu_baseline:

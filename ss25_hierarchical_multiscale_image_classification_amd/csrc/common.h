@@ -119,6 +119,9 @@ struct Plan {
   int fuse_stem;  // 1: stem conv + max-pool in one kernel (default); 0: separate kernels (keeps the stem tap)
   int stem_strip; // uint8 input: 1 = strip kernel (default), 0 = tile kernel with the LDS table (first form)
   int l1_fused;   // 1 = a layer1 BasicBlock is one kernel (default), 0 = conv1 and conv2 as separate launches
+  int pool_head;  // 1 = the last conv's epilogue reduces the 7x7 map per image (partial sums in `part`, head_pool_kernel
+                  // finishes), 0 = it stores the fp32 map blk[7] and head_kernel reads it (HIPAC_POOL_HEAD=0; fp32 / fp16x3)
+  size_t part;    // float[ceil(gc * 49 / 256)][2][kPoolSlots = 7][2][512] partial sums of the global average pool
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]
   size_t stem;    // T[bc,112,112,64]
@@ -157,6 +160,9 @@ int launch_gemm_f32(const float* a, long long sam, long long sak, const float* b
 int launch_nchw_to_nhwc4(const float* x, void* out, int n, int precision, hipStream_t s);
 int launch_head(const float* last, int n, const float* fc_w, const float* fc_b, int num_classes,
                 float* feats, float* logits, int64_t* labels, hipStream_t s);
+int launch_head_pool(const float* part, int n, const float* fc_w, const float* fc_b, int num_classes,
+                     float* feats, float* logits, int64_t* labels, hipStream_t s);
+bool halo_pool_compiled();  // conv_bf16.hip: was the 16x16x32 halo kernel with the direct epilogue compiled in?
 int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, int H, int W, float* dst,
                       hipStream_t s);
 

@@ -5,6 +5,7 @@ int run_trunk_bf16(const Net& net, const Plan& p, char* ws, const void* xin, int
                    hipStream_t s, int first, int last) {
   return run_trunk<__bf16>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
 }
+bool halo_pool_compiled() { return halo_pool_available<__bf16, false>(); }
 }  // namespace hipac
 
 #ifdef HIPAC_HALO_STAMPS

@@ -2636,18 +2636,23 @@ static inline int ensure_dynamic_lds(const void* kern, int lds, bool* done) {
 #endif
 // the halo kernel of a layer: the 16x16x32 form for the plain 16-bit precisions on 256 x 128 tiles, else the 32x32x16 form
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32, bool SPLIT, int PCIN,
-          bool DBLW>
+          bool DBLW, bool POOL = false>
 static auto halo_kernel_of() {
   if constexpr (HIPAC_HALO_MF16 && !SPLIT && sizeof(T) == 2 && BM == 256 && BN == 128)
-    return conv3x3_halo16_kernel<T, CIN, COUT, H, W, BM, BN, NSW, RELU, RESID, OUTF32, PCIN>;
-  else
+    return conv3x3_halo16_kernel<T, CIN, COUT, H, W, BM, BN, NSW, RELU, RESID, OUTF32, PCIN, POOL>;
+  else {
+    static_assert(!POOL, "the pooled epilogue exists in the 16x16x32 halo kernel only");
     return conv3x3_halo_kernel<T, CIN, COUT, H, W, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT, 2, 2, 2, PCIN, DBLW>;
+  }
 }
+// does the last conv of the network (512 -> 512, 7 x 7) have the pooled epilogue in this build and precision?
+template <typename T, bool SPLIT>
+constexpr bool halo_pool_available() { return HIPAC_HALO_MF16 && HIPAC_H16_DIRECT && HIPAC_USE_HALO && !HIPAC_HALO_BIG && !SPLIT && sizeof(T) == 2; }
 template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, bool RELU, bool RESID,
-          bool OUTF32, bool STEM = false, bool SPLIT = false>
+          bool OUTF32, bool STEM = false, bool SPLIT = false, bool POOL = false>
 static int launch_conv(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s,
                        const char* zero_page = nullptr) {
   constexpr int PAD = STEM ? 0 : KS / 2;
@@ -2697,7 +2702,7 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     constexpr int NSW = DBLW ? 2 : ((A_BYTES + 3 * BN * 128 <= 80 * 1024) ? 3 : 2);  // deepest ring that keeps 2 workgroups/CU
     constexpr int RING = NSW * BN * 128 * (DBLW ? 2 : 1);
     constexpr int LDS = A_BYTES + (RING > STG ? RING : STG);
-    auto kern = halo_kernel_of<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT, 0, DBLW>();
+    auto kern = halo_kernel_of<T, CIN, COUT, HI, WI, BM, BN, NSW, RELU, RESID, OUTF32, SPLIT, 0, DBLW, POOL>();
     static bool attr_done[kMaxDevices] = {};  // the attribute is per device; a benign race at worst repeats the call
     if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
     const int n_mtiles = (M + BM - 1) / BM;
@@ -2883,11 +2888,20 @@ struct OpRange {
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
 template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false>
 static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
-                     hipStream_t s, OpRange& ops, bool fuse_blocks = false) {
+                     hipStream_t s, OpRange& ops, bool fuse_blocks = false, void* pool_part = nullptr) {
   constexpr int HO = HI / STRIDE;
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
+  // second conv of the stage's second block; for the network's last one (LAST) either the fp32 map or, with `pool_part`,
+  // the per-image partial sums of the global average pool (halo16.h, POOL)
+  auto launch_last = [&](const void* in_, const void* resid_, void* out_) -> int {
+    if constexpr (LAST && halo_pool_available<T, SPLIT>()) {
+      if (pool_part)
+        return launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, true, false, SPLIT, true>(in_, bw1[1], resid_, pool_part, n, s, z);
+    }
+    return launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST, false, SPLIT>(in_, bw1[1], resid_, out_, n, s, z);
+  };
   if constexpr (CI == 64 && CO == 64 && HI == 56 && STRIDE == 1 && sizeof(T) == 2 && !SPLIT) {
     if (fuse_blocks) {
       // layer1: each BasicBlock is one launch (conv1 -> conv2 + shortcut on chip); the conv2 op slots stay empty
@@ -2919,7 +2933,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
       if (ops.take())
         HIPAC_TRY((launch_conv_projk<T, CO, HO, CI>(tmp, bw[1], net.down[stage - 1], net.bias_c2p[stage - 1], x, o0, n, s, z)));
       if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false, false, SPLIT>(o0, bw1[0], nullptr, tmp, n, s, z)));
-      if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST, false, SPLIT>(tmp, bw1[1], o0, o1, n, s, z)));
+      if (ops.take()) HIPAC_TRY((launch_last(tmp, o0, o1)));
       return 0;
     }
   }
@@ -2942,7 +2956,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, false, false, SPLIT>(tmp, bw[1], idt, o0, n, s, z)));
   // block 1
   if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false, false, SPLIT>(o0, bw1[0], nullptr, tmp, n, s, z)));
-  if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, true, LAST, false, SPLIT>(tmp, bw1[1], o0, o1, n, s, z)));
+  if (ops.take()) HIPAC_TRY((launch_last(tmp, o0, o1)));
   return 0;
 }
 
@@ -3020,7 +3034,8 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
                                                        p.l1_fused != 0)));
   HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
   HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops,
+                                                        false, p.pool_head && halo_pool_available<T, SPLIT>() ? ws + p.part : nullptr)));
   return 0;
 }
 

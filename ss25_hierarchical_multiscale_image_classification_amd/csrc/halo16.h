@@ -102,7 +102,34 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
 #define HIPAC_H16_AHEAD (HIPAC_H16_ASM ? 3 : 2)  // activation fragments in flight ahead of the sub-tile whose MFMAs are being issued
 #endif
 
-template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32, int PCIN = 0>
+// POOL (the network's last conv: OUTF32, RELU): instead of storing the fp32 map [n][H*W][COUT] (0.1 MB per patch, read back by
+// the head kernel), the epilogue reduces the tile's pixels per IMAGE -- the global average pool's sum -- and writes partial
+// sums float[n_mtiles][WM][kPoolSlots][2][COUT] (`outp`; [..][0] = grid-2^-10 parts, [..][1] = remainders, see the epilogue):
+// slot r of M-tile mt = image (mt * BM) / (H*W) + r.  Per lane the eight
+// pixels are summed in order into the accumulator set of the sub-tile's first image (A) or of the next one (B; a 16-pixel
+// sub-tile meets at most two images), a set is reduced over the 16 lanes of a row (four DPP rotations) and written when the
+// walk leaves its image: no atomics, one fixed order, so the features are reproducible bit for bit.  hipac_capi.hip's
+// head_pool_kernel adds the <= 2 x WM partial sums of an image in a fixed order, divides by H*W and applies the fc.
+constexpr int kPoolSlots = 7;  // images a 256-pixel tile of 49-pixel maps can meet (1 + 5 x 49 + 10)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row, in every lane (lane n adds its partners in the order n+8, n+4, n+2, n+1 mod 16)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x122>(v);  // row_ror:2
+  return dpp_add<0x121>(v);  // row_ror:1
+}
+#else
+__device__ inline float row16_sum(float v) { return v; }
+#endif
+
+template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32, int PCIN = 0,
+          bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                                 const float* __restrict__ bias, const T* __restrict__ resid,
                                                                 void* __restrict__ outp, int M, int n_img, int n_mtiles,
@@ -125,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   constexpr int PCC = PCIN / 64;                    // projection K steps (0: no folded projection)
   constexpr int NSTEP = 9 * CC + PCC;
   static_assert(sizeof(T) == 2, "16-bit operands");
+  static_assert(!POOL || (OUTF32 && RELU && HIPAC_H16_DIRECT && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16),
+                "pooled epilogue: the fp32 form of the direct epilogue, maps of more than 16 pixels");
   static_assert(PCIN % 64 == 0 && (PCIN == 0 || !RESID), "folded projection replaces the residual input");
   static_assert((BM == 128 || BM == 256) && WTN % 16 == 0 && COUT % BN == 0 && CIN % 64 == 0 && MT <= 8, "tile shape");
   static_assert((BN / 8) % 4 == 0, "W piece split");
@@ -485,10 +514,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       }
     }
     HALO_STAMP(t_pref);
+    // pooled epilogue state: S[..][0] = sums of the values rounded to the grid 2^-10, S[..][1] = sums of the remainders rounded
+    // to the grid 2^-29, for the image the walk over the wave's pixels is in
+    [[maybe_unused]] f32x4 poolS[NT][2];
+    [[maybe_unused]] int pool_slot = 0, pool_bound = 0;  // that image's slot; first pixel of the image after it
+    [[maybe_unused]] auto pool_flush = [&](int slot_) {
+      float* dst = reinterpret_cast<float*>(outp) + (((size_t)(mt * WM + wm) * kPoolSlots + slot_) * 2) * COUT + n0 + wn * WTN + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = row16_sum(poolS[j][part][e]);
+          if (n16 == 0) *reinterpret_cast<float4*>(dst + part * COUT + 16 * j) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    if constexpr (POOL) {
+      constexpr int IMG = H * W;
+      const int mwave = m0 + wm * WPX;
+      pool_slot = mwave / IMG - m0 / IMG;
+      pool_bound = (mwave / IMG + 1) * IMG;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) poolS[j][0] = poolS[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     static_for<MT>([&](auto SUB) {
       constexpr int i = decltype(SUB)::value;
       const int m = mw0 + 16 * i;
-      if constexpr (OUTF32) {
+      if constexpr (POOL) {
+        // An EXACT sum, so that an image's features do not depend on where in the batch (which lanes, which tile) it sits:
+        // v = hi + lo + r with hi on the grid 2^-10 (v + C - C rounds to the grid of C's ulp), lo = (v - hi) on the grid
+        // 2^-29, |r| <= 2^-30.  Sums of such terms are exact in fp32 while sum(hi) < 2^14 (|lo| <= 2^-11: 49 of them stay
+        // below 2^-5 = 2^24 grid steps), whatever the order -- per-lane sums, the DPP tree, head_pool_kernel.
+        f32x4 hi[NT], lo[NT];
+        const bool live = m < M;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+          if constexpr (RESID) {
+            const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, rq32[i][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = live ? fmaxf(v[e], 0.f) : 0.f;
+            hi[j][e] = (v[e] + 12288.0f) - 12288.0f;                       // C = 1.5 x 2^13: ulp 2^-10
+            lo[j][e] = ((v[e] - hi[j][e]) + 0.0234375f) - 0.0234375f;     // C = 1.5 x 2^-6: ulp 2^-29
+          }
+        }
+        if (m0 + wm * WPX + 16 * i + 15 < pool_bound) {  // (uniform) the whole sub-tile lies in the current image
+#pragma unroll
+          for (int j = 0; j < NT; ++j) poolS[j][0] += hi[j], poolS[j][1] += lo[j];
+        } else {  // an image ends inside this sub-tile (or right in front of it): finish it, start the next one
+          const bool in_a = m < pool_bound;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) poolS[j][0][e] += in_a ? hi[j][e] : 0.f, poolS[j][1][e] += in_a ? lo[j][e] : 0.f;
+          pool_flush(pool_slot);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) poolS[j][0][e] = in_a ? 0.f : hi[j][e], poolS[j][1][e] = in_a ? 0.f : lo[j][e];
+          ++pool_slot, pool_bound += H * W;
+        }
+        if constexpr (i == MT - 1) {
+          // the image the walk ends in (slot <= kPoolSlots - 1); if the wave's last pixel closed an image, an all-zero set
+          // for a slot nobody reads -- unless it would lie outside the buffer
+          if (pool_slot < kPoolSlots) pool_flush(pool_slot);
+        }
+      } else if constexpr (OUTF32) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
@@ -552,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       atomicAdd(&g_halo_stamps[7], t_setup - t_start);
     }
 #endif
-    prev_full = (m0 + BM <= M);
+    prev_full = !POOL && (m0 + BM <= M);  // (POOL: the number of stores depends on the images the tile meets)
     continue;  // next tile
   }
   // the residual of the first 32-pixel group is requested here, not from inside the last K step as in the 32x32 kernel: its

@@ -62,6 +62,7 @@ Plan make_plan(int batch, int precision) {
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
   p.l1_fused = wide_mode(precision) ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
+  p.pool_head = (wide_mode(precision) || !halo_pool_compiled()) ? 0 : env_int("HIPAC_POOL_HEAD", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -90,6 +91,7 @@ Plan make_plan(int batch, int precision) {
   p.blk[5] = take(g * 14 * 14 * 256 * e);
   p.blk[6] = take(g * 7 * 7 * 512 * e);
   p.blk[7] = take(g * 7 * 7 * 512 * 4);
+  p.part = take(((g * 49 + 255) / 256) * 2 * 7 * 2 * 512 * 4);
   p.total = off;
   return p;
 }
@@ -178,6 +180,68 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ las
       }
     labels[b] = best;
   }
+}
+
+// The same head over the partial sums the last conv's pooled epilogue leaves (halo16.h, POOL): image b = pixels
+// [49 b, 49 b + 48] of the flattened 7x7 maps meets at most two 256-pixel tiles mt and both 128-pixel wave halves wm of
+// each; part[mt][wm][slot = b - (256 mt) / 49][2][512] = (sum of the pixel values rounded to the grid 2^-10, sum of the
+// remainders on the grid 2^-29): both sums are EXACT in fp32 (halo16.h), so the features do not depend on how the image's
+// pixels were spread over lanes, waves and tiles -- the same patch gives the same bits at any position of any batch.
+// Only the (mt, wm) pairs that overlap the image are read (slots a wave never met are not written).
+__global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ part, const float* __restrict__ fc_w,
+                                                        const float* __restrict__ fc_b, int num_classes,
+                                                        float* __restrict__ feats, float* __restrict__ logits,
+                                                        long long* __restrict__ labels) {
+  __shared__ float red[4][16];
+  __shared__ float lg[16];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int p0 = 49 * b, p1 = p0 + 48;
+  float h0 = 0.f, h1 = 0.f, l0 = 0.f, l1 = 0.f;  // exact sums (grid 2^-10 parts, grid 2^-29 remainders): any order gives these bits
+  for (int mt = p0 >> 8; mt <= (p1 >> 8); ++mt)
+    for (int wm = 0; wm < 2; ++wm) {
+      const int w0 = mt * 256 + wm * 128;
+      if (w0 + 127 < p0 || w0 > p1) continue;  // this wave half holds no pixel of the image
+      const int slot = b - (mt * 256) / 49;
+      const float* src = part + (((size_t)(mt * 2 + wm) * 7 + slot) * 2) * 512 + tid * 2;
+      const float2 vh = *reinterpret_cast<const float2*>(src), vl = *reinterpret_cast<const float2*>(src + 512);
+      h0 += vh.x, h1 += vh.y;
+      l0 += vl.x, l1 += vl.y;
+    }
+  const float f0 = (h0 + l0) / 49.0f, f1 = (h1 + l1) / 49.0f;
+  if (feats) *reinterpret_cast<float2*>(feats + (size_t)b * 512 + tid * 2) = make_float2(f0, f1);
+  if (num_classes <= 0 || (!logits && !labels)) return;
+  for (int j = 0; j < num_classes; ++j) {
+    const float2 w = *reinterpret_cast<const float2*>(fc_w + (size_t)j * 512 + tid * 2);
+    float v = f0 * w.x + f1 * w.y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6][j] = v;
+  }
+  __syncthreads();
+  if (tid < num_classes) {
+    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + fc_b[tid];
+    lg[tid] = v;
+    if (logits) logits[(size_t)b * num_classes + tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0 && labels) {
+    int best = 0;
+    float bv = lg[0];
+    for (int j = 1; j < num_classes; ++j)
+      if (lg[j] > bv) {  // strict: first maximum wins, as torch.argmax
+        bv = lg[j];
+        best = j;
+      }
+    labels[b] = best;
+  }
+}
+
+int launch_head_pool(const float* part, int n, const float* fc_w, const float* fc_b, int num_classes, float* feats,
+                     float* logits, int64_t* labels, hipStream_t s) {
+  hipLaunchKernelGGL(head_pool_kernel, dim3(n), dim3(256), 0, s, part, fc_w, fc_b, num_classes, feats, logits,
+                     (long long*)labels);
+  return (int)hipGetLastError();
 }
 
 int launch_head(const float* last, int n, const float* fc_w, const float* fc_b, int num_classes, float* feats,
@@ -608,9 +672,12 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
       }
       int rc = trunk(net, p, ws, nullptr, 0, 0, gn, s, kNumEarlyOps, kNumOps - 1);
       if (rc) return rc;
-      rc = launch_head((const float*)(ws + p.blk[7]), gn, net.fc_w, net.fc_b, net.num_classes,
-                       feats ? feats + (size_t)g0 * 512 : nullptr,
-                       logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s);
+      rc = (p.pool_head ? launch_head_pool((const float*)(ws + p.part), gn, net.fc_w, net.fc_b, net.num_classes,
+                                           feats ? feats + (size_t)g0 * 512 : nullptr,
+                                           logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s)
+                        : launch_head((const float*)(ws + p.blk[7]), gn, net.fc_w, net.fc_b, net.num_classes,
+                                      feats ? feats + (size_t)g0 * 512 : nullptr,
+                                      logits ? logits + (size_t)g0 * net.num_classes : nullptr, labels ? labels + g0 : nullptr, s));
       HIPAC_REQUIRE(rc == 0, rc, "forward: head launch failed (%d)", rc);
     }
     return 0;
@@ -706,6 +773,15 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
     const int ch[4] = {64, 128, 256, 512}, hw[4] = {56, 28, 14, 7};
     src = ws + p.blk[blk], C = ch[st], H = hw[st];
     is_f32 = blk == 7;
+    if (blk == 7 && p.pool_head) {
+      // the forward left the pooled partial sums, not the map: the last conv runs once more with its fp32-map epilogue
+      // (same accumulators) on the activations still in the workspace
+      Plan q = p;
+      q.pool_head = 0;
+      auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+      int rc_t = trunk(w->net, q, (char*)workspace, nullptr, 0, 0, batch, (hipStream_t)stream, kNumOps - 1, kNumOps - 1);
+      HIPAC_REQUIRE(rc_t == 0, rc_t, "tap: re-running the last conv failed (%d)", rc_t);
+    }
   }
   int rc = launch_tap_export(src, is_f32, w->net.precision, batch, C, H, H, dst, (hipStream_t)stream);
   HIPAC_REQUIRE(rc == 0, rc, "tap: launch failed (%d)", rc);

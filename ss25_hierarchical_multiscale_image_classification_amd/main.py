@@ -143,6 +143,8 @@ def try_open(name: str, make):
         return make()
     except Exception as e:  # noqa: BLE001 -- whatever the reader raises for a truncated / foreign file
         print(f"[ERROR] Could not open {name}: {type(e).__name__}: {e}", flush=True)
+        if int(os.environ.get("RANK", "0")) != 0:  # the launcher relays rank 0's stdout only: the other ranks report on stderr too
+            print(f"[ERROR] rank {os.environ['RANK']}: could not open {name}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         return None
 
 

@@ -233,6 +233,10 @@ def test_bench_two_ranks_default_line(tmp_path):
     assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
     wsi = rec["wsi"]["3000x3000"]
     assert "error" not in wsi and wsi["slides"] == 2 and wsi["n_gpus"] == 2 and wsi["s_per_slide"] > 0
+    # N > 1: the load balance of one-slide-per-rank is in the line (every rank's kept windows and own time)
+    assert len(wsi["kept_per_rank"]) == 2 and min(wsi["kept_per_rank"]) > 0 and wsi["kept_all_ranks"] == sum(wsi["kept_per_rank"])
+    assert 0 < wsi["rank_s_min"] <= wsi["rank_s_max"] <= wsi["s_per_slide"] * 1.5 and len(wsi["rank_s_per_slide"]) == 2
+    assert all("(fused)" not in o["op"] for o in rec["per_op"])
     assert rec["simclr"]["n_gpus"] == 2 and rec["simclr"]["value"] > 0 and rec["simclr"]["final_loss"] > 0
 
 
@@ -265,7 +269,8 @@ def test_cli_unreadable_slide_costs_that_slide_only(tmp_path, world):
         r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         if bad:
-            assert "[ERROR] Could not open tumor_002" in r.stdout and "[WARNING] Failed to parse XML for tumor_003" in r.stdout
+            # (--world_size 2: slide 1 of 3 belongs to rank 1, whose stdout the launcher does not relay: it reports on stderr)
+            assert "ould not open tumor_002" in r.stdout + r.stderr and "[WARNING] Failed to parse XML for tumor_003" in r.stdout
         outs.append(d)
     f0, f1 = np.load(outs[0] / "patch_features_1.npy"), np.load(outs[1] / "patch_features_1.npy")
     assert f0.shape[0] > 10 and np.array_equal(f0, f1)
