@@ -153,7 +153,10 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
 /* Debug / test tap: copy one intermediate activation of the LAST forward run
  * with this workspace to `dst` as float32 NCHW.  `tap`: 0 stem(after relu),
  * 1 maxpool, 2..9 output of block 0..7.  Used only by the layer-wise parity
- * tests. */
+ * tests.  Tap 9: by default the last conv leaves per-image partial sums of the
+ * global average pool, not its fp32 map (round 4; HIPAC_POOL_HEAD=0 restores the
+ * map); the tap then re-runs that conv with the map epilogue into the workspace
+ * (which it therefore writes, `const` notwithstanding) before exporting it. */
 int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batch, int tap,
                        float* dst, void* stream);
 
