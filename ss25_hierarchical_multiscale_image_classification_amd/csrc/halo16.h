@@ -92,8 +92,12 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
 #define HIPAC_H16_DIRECT 1  // 1: epilogue straight from the accumulators (v_permlane16_swap pairs 16-lane rows into 16-byte
                             // items), the next tile's band AND first weight tiles prefetched behind it; 0: staged through LDS
 #endif
+#ifndef HIPAC_H16_RESID_MFMA
+#define HIPAC_H16_RESID_MFMA 1  // 1: the residual is added by the matrix pipe (identity "weights" over the residual tile brought
+                                // into LDS by DMA, after the last tap); 0: loaded into registers and added in the epilogue
+#endif
 #ifndef HIPAC_H16_ABL
-#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -151,6 +155,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   constexpr int NTILES_N = COUT / BN;
   constexpr int PCC = PCIN / 64;                    // projection K steps (0: no folded projection)
   constexpr int NSTEP = 9 * CC + PCC;
+  constexpr bool RESID_MFMA = RESID && HIPAC_H16_RESID_MFMA && HIPAC_H16_ASM && HIPAC_H16_DIRECT;  // see "the residual, added on the matrix pipe"
+  constexpr bool EPI_RESID = RESID && !RESID_MFMA;  // the epilogue loads and adds the residual itself
   static_assert(sizeof(T) == 2, "16-bit operands");
   static_assert(!POOL || (OUTF32 && RELU && HIPAC_H16_DIRECT && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16),
                 "pooled epilogue: the fp32 form of the direct epilogue, maps of more than 16 pixels");
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       asm("v_and_b32 %0, %1, %2" : "=v"(em) : "s"(tapmask), "v"(epk));
       int a_addr[MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
+      for (int i = 0; i < MT; ++i) a_addr[i] = (HIPAC_H16_ABL & 16) ? a_in + 2048 * i : ((em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i);
       k_step(wst, a_addr, [&] {
         // the next step's weight DMA is issued from inside the MFMA stream (its slot was freed by this step's barrier)
         if (!(HIPAC_H16_ABL & 2) && s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
@@ -459,6 +465,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     }
   }
 
+  if constexpr (RESID_MFMA) {
+    // ---- the residual, added on the matrix pipe.  A direct epilogue would have to LOAD it in the accumulator layout: 16 bytes
+    // per lane with neighbouring lanes on different pixels -- four times the address-coalescer cycles of a contiguous read,
+    // in bursts of 16 loads per wave that queue in front of the other workgroup's weight DMA (measured: 6-8 k cycles to issue
+    // them, 7-10 k more in the store loop; the residual convs' epilogues were 2x the others').  Instead the tile's residual,
+    // [256 px][128 ch], comes in by LDS-DMA in the band's own row format (full 128-byte lines per pixel, no registers): the
+    // 64 channels of the wn = 0 waves into the band region, those of the wn = 1 waves into the weight ring (both are free
+    // now), and every accumulator takes ONE more MFMA: D += I x R with I the 16 x 32 identity fragment that picks the tile's
+    // 16 channels out of the 32 of a k32 step.  1.0 x r is exact and lands in the fp32 accumulator: the same single rounding
+    // as the epilogue's `+ (float)r`.  32 MFMAs + 16 fragment reads per wave, one DMA round trip.
+    __builtin_amdgcn_s_barrier();  // every wave has finished the last K step: band and ring are free
+    const rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(resid), M * COUT * 2);
+    {
+      // piece p of chunk c = slots 8p .. 8p+7 (slot = pixel - m0); a wave's pieces share p's parity: per-lane swizzle term
+      const int r_lane = (prow * COUT + (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 8) * 2;
+      const int r_base = (m0 * COUT + n0) * 2;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < BM / 8 / 4; ++k) {
+          const int p = wave + 4 * k;
+          buffer_load_lds16(r_rsrc, (c ? Wbuf : Abuf) + p * 1024, r_lane + r_base + c * 128 + p * (8 * COUT * 2), 0);
+        }
+    }
+    static_assert(A_BYTES >= BM * 128 && S_BYTES >= BM * 128 && BN == 128, "residual tile: one 64-channel chunk per region");
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // identity fragments: lane (n, g) holds k = 8 g .. 8 g + 7 of row n; row n of an EVEN 16-channel tile is k = n of its
+    // k32 step (channels 32 kk .. + 31), of an ODD tile k = 16 + n
+    frag ident[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ident[o][e] = (g == 2 * o + (n16 >> 3) && e == (n16 & 7)) ? (T)1.0f : (T)0.0f;
+    {
+      const int r0 = wm * WPX + pn;  // slot of sub-tile 0's pixel
+      const unsigned rb = lds0 + (unsigned)((wn ? Wbuf : Abuf) - ring) + (unsigned)(r0 * 128 + ((g ^ ((r0 >> 1) & 7)) << 4));
+      frag rf[4];
+      // reads: (i, kk) in the order (0,0) (0,1) (1,0) ...; two sub-tiles in flight
+      static_for<2>([&](auto S) { lds_read16<(decltype(S)::value >> 1) * 2048>(rf[decltype(S)::value], (decltype(S)::value & 1) ? rb ^ 64u : rb); });
+      static_for<2 * MT>([&](auto S) {
+        constexpr int s2 = decltype(S)::value, i = s2 >> 1, kk = s2 & 1;
+        if constexpr (s2 + 2 < 2 * MT) lds_read16<((s2 + 2) >> 1) * 2048>(rf[(s2 + 2) & 3], ((s2 + 2) & 1) ? rb ^ 64u : rb);
+        wait_lgkmcnt<(s2 + 2 < 2 * MT) ? 2 : (2 * MT - 1 - s2)>();
+        Asm16<T>::mfma(acc[i][2 * kk], ident[0], rf[s2 & 3]);
+        Asm16<T>::mfma(acc[i][2 * kk + 1], ident[1], rf[s2 & 3]);
+      });
+    }
+  }
   // ---- epilogue -------------------------------------------------------------------------------
   HALO_STAMP(t_loop);
 #if HIPAC_H16_ASM
@@ -478,11 +533,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     const int c_lane = n0 + wn * WTN + 16 * (g & 1) + 8 * (g >> 1);  // + 32 jp: first of the 8 channels this lane stores
     // ALL of the tile's residual loads are requested up front (the K loop's fragment registers are free now): vector-memory
     // operations retire in order, so a load requested later would queue behind the next tile's band and weight DMA below
-    u32x4 rq[MT][RESID && !OUTF32 ? NT / 2 : 1];
-    u32x2 rq32[MT][RESID && OUTF32 ? NT : 1];
+    u32x4 rq[MT][EPI_RESID && !OUTF32 ? NT / 2 : 1];
+    u32x2 rq32[MT][EPI_RESID && OUTF32 ? NT : 1];
     auto load_resid_d = [&](auto SUB) {
       constexpr int i = decltype(SUB)::value;
-      if constexpr (RESID) {
+      if constexpr (EPI_RESID) {
         int m = mw0 + 16 * i;
         m = m < M ? m : M - 1;  // unconditional load from a valid row (tail rows are never stored)
         if constexpr (OUTF32) {
@@ -551,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-          if constexpr (RESID) {
+          if constexpr (EPI_RESID) {
             const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, rq32[i][j]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
@@ -588,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-          if constexpr (RESID) {
+          if constexpr (EPI_RESID) {
             const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, rq32[i][j]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
@@ -605,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
 #pragma unroll
         for (int jp = 0; jp < NT / 2; ++jp) {
           unsigned R[4] = {0u, 0u, 0u, 0u};
-          if constexpr (RESID) {
+          if constexpr (EPI_RESID) {
             R[0] = rq[i][jp][0], R[1] = rq[i][jp][1], R[2] = rq[i][jp][2], R[3] = rq[i][jp][3];
             permlane16_swap(R[0], R[2]);  // -> (R[0], R[1]) = this lane's 4 channels of tile 2 jp, (R[2], R[3]) = of tile 2 jp + 1
             permlane16_swap(R[1], R[3]);
@@ -615,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
           for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * jp + jj;
             float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-            if constexpr (RESID) {
+            if constexpr (EPI_RESID) {
               const typename E::vec4 rr = __builtin_bit_cast(typename E::vec4, u32x2{R[2 * jj], R[2 * jj + 1]});
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
