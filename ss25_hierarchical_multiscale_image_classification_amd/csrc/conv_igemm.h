@@ -1267,6 +1267,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
 
 }  // namespace hipac
 #include "halo16.h"
+#include "band16.h"
 namespace hipac {
 
 // ---------------------------------------------------------------------------------------
@@ -2651,6 +2652,34 @@ constexpr bool halo_pool_available() { return HIPAC_HALO_MF16 && HIPAC_H16_DIREC
 template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
+#ifndef HIPAC_BAND16
+#define HIPAC_BAND16 1  // the 3x3 / stride 2 entry convs of layers 2-4 on the half-chunk band kernel (band16.h); layer2's projection
+                        // shortcut then folds into its block's second conv as layers 3-4's do
+#endif
+#ifndef HIPAC_BAND16_S1
+#define HIPAC_BAND16_S1 0  // ... the stride-1 ones too (measured: 2-3 % SLOWER than halo16 -- the hidden band round trip does not
+                           // pay for twice the per-tap address work and 64-byte weight rows; they stay on the halo16 kernel)
+#endif
+template <typename T, int CIN, int COUT, int HO, int STRIDE, bool RELU, bool RESID, int PCIN>
+static int launch_band16(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s, const void* wgt_p = nullptr,
+                         const float* bias = nullptr) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int LEAD = HO + 1, TRAIL = STRIDE == 1 ? HO + 1 : 0;
+  constexpr int NPW = (4 + LEAD + BM + TRAIL + 63) / 64;
+  constexpr int LDS = 2 * NPW * 4 * 1024 + HIPAC_B16_NSLOT * 8192;
+  auto kern = conv3x3_band16_kernel<T, CIN, COUT, HO, HO, STRIDE, BM, BN, RELU, RESID, PCIN>;
+  static bool attr_done[kMaxDevices] = {};
+  if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+  const int M = n * HO * HO;
+  const int n_mtiles = (M + BM - 1) / BM;
+  const int mt8 = (n_mtiles + 7) / 8 * 8;
+  const int n_vtiles = mt8 * (COUT / BN);
+  dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, bias ? bias : w.bias, (const T*)resid, (T*)out, M, n, n_mtiles,
+                     (const T*)wgt_p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, int CIN, int COUT, int HI, int WI, int KS, int STRIDE, bool RELU, bool RESID,
           bool OUTF32, bool STEM = false, bool SPLIT = false, bool POOL = false>
 static int launch_conv(const void* in, const ConvW& w, const void* resid, void* out, int n, hipStream_t s,
@@ -2689,6 +2718,10 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
     dim3 grid(n_vtiles < 256 ? n_vtiles : 256);  // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)resid, out, M, n,
                        n_mtiles, zero_page, (const T*)nullptr);
+  } else if constexpr (HIPAC_BAND16_S1 && HIPAC_HALO_MF16 && KS == 3 && STRIDE == 1 && !SPLIT && sizeof(T) == 2 && !OUTF32 && COUT % 128 == 0 && HI == WI) {
+    return launch_band16<T, CIN, COUT, HI, 1, RELU, RESID, 0>(in, w, resid, out, n, s);
+  } else if constexpr (HIPAC_BAND16 && HIPAC_HALO_MF16 && KS == 3 && STRIDE == 2 && !SPLIT && sizeof(T) == 2 && !OUTF32 && !RESID && COUT % 128 == 0 && HI == WI) {
+    return launch_band16<T, CIN, COUT, HI / 2, 2, RELU, false, 0>(in, w, nullptr, out, n, s);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {
     constexpr int BN = COUT >= 128 ? 128 : 64;
     // 256-pixel tiles (each wave 128 px x 64 ch: 0.75 LDS reads per MFMA, half the weight DMA per
@@ -2748,6 +2781,8 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
 template <typename T, int CO, int HO, int PCIN>
 static int launch_conv_projk(const void* tmp, const ConvW& w2, const ConvW& wp, const float* bias_sum, const void* xblk, void* out,
                              int n, hipStream_t s, const char* zero_page) {
+  if constexpr (HIPAC_BAND16_S1 && HIPAC_HALO_MF16 && sizeof(T) == 2)
+    return launch_band16<T, CO, CO, HO, 1, true, false, PCIN>(tmp, w2, xblk, out, n, s, wp.w, bias_sum);
   constexpr int BN = 128;
   constexpr int A256 = halo_band_pieces(HO, 256) * 1024;
   constexpr int BM = (HIPAC_HALO_BM256 && A256 + 2 * BN * 128 <= 80 * 1024) ? 256 : 128;
@@ -2924,7 +2959,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   }
   // block 0
   const void* idt = x;
-  if constexpr (STRIDE == 2 && sizeof(T) == 2 && !SPLIT && CO >= 256) {
+  if constexpr (STRIDE == 2 && sizeof(T) == 2 && !SPLIT && (CO >= 256 || (HIPAC_BAND16 && HIPAC_HALO_MF16))) {
     if (net.projk && net.bias_c2p[stage - 1]) {
       // layers 3, 4: plain 3x3/2 entry conv; the projection rides in the SECOND conv as extra K steps (its op slot is empty)
       if (ops.take())

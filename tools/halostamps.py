@@ -21,7 +21,7 @@ net.forward(u8)
 torch.cuda.synchronize()
 names = [n for n, _ in bench.OPS]
 for i, name in enumerate(names):
-    if not (name[0] == "l" and name[1] in "234" and "b0c1" not in name):
+    if not (name[0] == "l" and name[1] in "234"):
         continue
     fn(buf, 1)
     net.run_ops(u8, i, i)
