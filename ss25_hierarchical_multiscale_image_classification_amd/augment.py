@@ -376,7 +376,7 @@ class DeviceClassifierLoader:
         self.epoch += 1
 
 
-def bench_input_pipeline(n_pairs: int = 256, P: int = 224, steps: int = 5, host_views: int = 48, device="cuda") -> dict:
+def bench_input_pipeline(n_pairs: int = 256, P: int = 224, steps: int = 5, host_views: int = 512, device="cuda") -> dict:
     """bench.py's ``simclr.input_pipeline``: view pairs per second of the device pipeline (batched draws + hipac_augment_views,
     wall clock around ``steps`` batches) next to the host transforms (Pillow, one thread, ``host_views`` views)."""
     import time
@@ -405,14 +405,18 @@ def bench_input_pipeline(n_pairs: int = 256, P: int = 224, steps: int = 5, host_
         draw_simclr_batch(list(range(n_pairs)), P, rng)
     t_draw = (time.perf_counter() - t1) / 20
     T = transforms.simclr_transform()
-    img = Image.fromarray(pool.patches[0].cpu().numpy(), "RGB")
+    # >= 512 views over 16 different patches (round 3 timed 48 views of ONE patch: the random crop sizes of so few draws
+    # made the figure swing 20x between runs), with a short warm-up so that Pillow's tables and the allocator are hot
+    imgs = [Image.fromarray(pool.patches[i % len(pool)].cpu().numpy(), "RGB") for i in range(16)]
+    for k in range(16):
+        T(imgs[k])
     t2 = time.perf_counter()
-    for _ in range(host_views):
-        T(img)
+    for k in range(host_views):
+        T(imgs[k % 16])
     t_host = (time.perf_counter() - t2) / host_views
     return {"patch": P, "pairs_per_batch": n_pairs, "device_pairs_per_s": n_batches * min(n_pairs, len(pool)) / dt,
             "host_draws_ms_per_batch": t_draw * 1e3,
-            "host_pillow_pairs_per_s_one_thread": 0.5 / t_host,
+            "host_pillow_pairs_per_s_one_thread": 0.5 / t_host, "host_views_timed": host_views, "host_patches": 16,
             "note": "device: batched numpy draws + hipac_augment_views (crop/resize, flip, ColorJitter, grayscale, normalise; "
                     "bit-exact vs Pillow); host: transforms.simclr_transform() = the reference's torchvision pipeline on Pillow, "
                     "PNG decoding not included on either side"}
