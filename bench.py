@@ -49,15 +49,15 @@ def _conv_macs(cin, cout, k, ho):
     return cin * cout * k * k * ho * ho
 
 
-L1_FUSED = os.environ.get("HIPAC_L1_FUSED", "1") != "0"  # a layer1 BasicBlock is one launch (block_c64_kernel)
-PROJK = os.environ.get("HIPAC_PROJK", "1") != "0"  # layers 3, 4: the projection shortcut is folded into the block's second conv
+L1_FUSED = os.environ.get("HIPAC_L1_FUSED", "1") != "0"  # a layer1 BasicBlock is one launch (block16_c64_kernel)
+PROJK = os.environ.get("HIPAC_PROJK", "1") != "0"  # layers 2-4: the projection shortcut is folded into the block's second conv
 OPS = [("stem7x7+pool", _conv_macs(3, 64, 7, 112)), ("(fused)", 0)]
 for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14), (256, 512, 7))):
     if _s == 0 and L1_FUSED:  # op slots of conv2 stay empty
         OPS += [("l1b0", 2 * _conv_macs(64, 64, 3, 56)), ("(fused)", 0), ("l1b1", 2 * _conv_macs(64, 64, 3, 56)), ("(fused)", 0)]
         continue
     _pm = _conv_macs(_ci, _co, 1, _ho)  # the 1x1/2 projection shortcut
-    if _s >= 2 and PROJK:  # its K steps ride in block0.conv2 (halo kernel, PCIN): the entry conv is plain, the slot empty
+    if _s >= 1 and PROJK:  # its K steps ride in block0.conv2 (halo16 kernel, PCIN): the entry conv is plain (band16 kernel), the slot empty
         OPS += [(f"l{_s+1}b0c1", _conv_macs(_ci, _co, 3, _ho)), ("(fused)", 0), (f"l{_s+1}b0c2+proj", _conv_macs(_co, _co, 3, _ho) + _pm)]
     elif _s in (1, 2):  # it rides inside the 3x3/2 launch (second accumulator set, empty op slot)
         OPS += [(f"l{_s+1}b0c1+proj", _conv_macs(_ci, _co, 3, _ho) + _pm), ("(fused)", 0), (f"l{_s+1}b0c2", _conv_macs(_co, _co, 3, _ho))]
@@ -67,8 +67,8 @@ for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
 assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 
-KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block_c64_kernel" if L1_FUSED else "conv3x3_c64_kernel", "l2b0c1+proj": "conv3x3s2_c64_kernel",
-                "l3b0c1+proj": "conv_glds_kernel", "l3b0c1": "conv_glds_kernel", "l4b0c1": "conv_glds_kernel", "l4proj": "conv_glds_kernel"}
+KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block16_c64_kernel" if L1_FUSED else "conv3x3_c64_kernel", "l2b0c1": "conv3x3_band16_kernel",
+                "l3b0c1": "conv3x3_band16_kernel", "l4b0c1": "conv3x3_band16_kernel", "l4proj": "conv_glds_kernel"}
 
 
 def kernel_of(op: str) -> str:

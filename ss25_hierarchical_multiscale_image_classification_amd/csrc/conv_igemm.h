@@ -2467,6 +2467,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_kernel(const T* __restri
 
 }  // namespace hipac
 #include "block_c64.h"
+#include "block16_c64.h"
 namespace hipac {
 
 // 3x3/2 max-pool, pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are
@@ -2652,6 +2653,9 @@ constexpr bool halo_pool_available() { return HIPAC_HALO_MF16 && HIPAC_H16_DIREC
 template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
+#ifndef HIPAC_BLK16
+#define HIPAC_BLK16 1  // the fused layer1 block on v_mfma_f32_16x16x32 (block16_c64.h); 0: the 32x32x16 form (block_c64.h)
+#endif
 #ifndef HIPAC_BAND16
 #define HIPAC_BAND16 1  // the 3x3 / stride 2 entry convs of layers 2-4 on the half-chunk band kernel (band16.h); layer2's projection
                         // shortcut then folds into its block's second conv as layers 3-4's do
@@ -2942,14 +2946,15 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
       // layer1: each BasicBlock is one launch (conv1 -> conv2 + shortcut on chip); the conv2 op slots stay empty
       const int per_xcd = 4 * ((n + 7) / 8);                   // strips on the busiest XCD
       const int grid = 8 * (per_xcd < 32 ? per_xcd : 32);      // persistent: one 8-wave workgroup per CU
+      auto blk_kern = HIPAC_BLK16 ? block16_c64_kernel<T> : block_c64_kernel<T>;
       if (ops.take()) {
-        hipLaunchKernelGGL((block_c64_kernel<T>), dim3(grid), dim3(512), 0, s, (const T*)x, (const T*)bw[0].w,
+        hipLaunchKernelGGL(blk_kern, dim3(grid), dim3(512), 0, s, (const T*)x, (const T*)bw[0].w,
                            bw[0].bias, (const T*)bw[1].w, bw[1].bias, (T*)o0, n);
         HIPAC_TRY((int)hipGetLastError());
       }
       (void)ops.take();
       if (ops.take()) {
-        hipLaunchKernelGGL((block_c64_kernel<T>), dim3(grid), dim3(512), 0, s, (const T*)o0, (const T*)bw1[0].w,
+        hipLaunchKernelGGL(blk_kern, dim3(grid), dim3(512), 0, s, (const T*)o0, (const T*)bw1[0].w,
                            bw1[0].bias, (const T*)bw1[1].w, bw1[1].bias, (T*)o1, n);
         HIPAC_TRY((int)hipGetLastError());
       }

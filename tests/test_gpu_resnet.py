@@ -151,15 +151,18 @@ def test_uint8_table_kernel_equals_normalize_then_forward_bitwise(monkeypatch):
 
 
 @pytest.mark.parametrize("n", [1, 7, 9, 70, 520])
-def test_layer1_fused_block_equals_separate_convs_bitwise(monkeypatch, n):
-    """Default: a layer1 BasicBlock is ONE kernel (conv1 -> I rows in LDS -> conv2 + shortcut, block_c64.h).
-    HIPAC_L1_FUSED=0 launches conv1 and conv2 separately (conv3x3_c64_kernel).  Same MFMA order, same
-    roundings: both block outputs and everything after them agree bit for bit -- at one image (4 strips,
-    28 idle workgroups per 32), at 7 and 9 (not multiples of the 8 XCDs), at 70 (workgroups walk several strips) and
-    at 520 (two sub-batches: 512 + 8)."""
+def test_layer1_fused_block_equals_separate_convs(monkeypatch, n):
+    """Default: a layer1 BasicBlock is ONE kernel (conv1 -> I rows in LDS -> conv2 + shortcut; block16_c64.h).
+    HIPAC_L1_FUSED=0 launches conv1 and conv2 separately (conv3x3_c64_kernel).  Rounds 2-3 ran both on
+    v_mfma_f32_32x32x16 with one accumulation order and asked for bit identity; the fused block now multiplies 32
+    channels per MFMA (16x16x32) where the separate convs still take 16, so the fp32 sums differ in their last bits and
+    a few outputs round to the neighbouring 16-bit value: every block output within two units of the last place of T,
+    features and logits within the precision's own noise -- at one image (4 strips, 28 idle workgroups per 32), at 7 and 9
+    (not multiples of the 8 XCDs), at 70 (workgroups walk several strips) and at 520 (two sub-batches: 512 + 8).  The fused
+    block ALONE is still deterministic and position-independent (test_sub_batching_and_determinism)."""
     sd = synth.seeded_resnet18_state_dict(4, num_classes=2)
     u8 = _border_patches(max(n, 3), 30 + n)[:n].cuda()
-    for prec in ("bf16", "fp16"):
+    for prec, ulp in (("bf16", 2.0 ** -8), ("fp16", 2.0 ** -11)):
         net = capi.PackedResNet18(sd, precision=prec)
         monkeypatch.setenv("HIPAC_L1_FUSED", "0")
         f0, l0, _ = net.forward(u8, want_logits=True)
@@ -169,8 +172,12 @@ def test_layer1_fused_block_equals_separate_convs_bitwise(monkeypatch, n):
         f1, l1, _ = net.forward(u8, want_logits=True)
         for t, ref in zip(tap_ids, taps0):
             got = net.tap(n, t)
-            assert torch.equal(got, ref), f"{prec} layer1 block {t - 2}: max diff {(got - ref).abs().max().item()}"
-        assert torch.equal(f0, f1) and torch.equal(l0, l1)
+            # elementwise: two units of the last place at the element's own magnitude (+ the same at the smallest normal scale
+            # of the map, for outputs that round across zero under the ReLU); the second block sees the first one's differences
+            bound = (2 + 6 * (t - 2)) * ulp * torch.maximum(ref.abs(), got.abs()) + 2 * ulp * 2.0 ** -4
+            bad = ((got - ref).abs() > bound)
+            assert not bool(bad.any()), f"{prec} layer1 block {t - 2}: {int(bad.sum())} outputs beyond the bound, max diff {(got - ref).abs().max().item()}"
+        assert rel(f1, f0) <= 40 * ulp and rel(l1, l0) <= 80 * ulp, (prec, rel(f1, f0), rel(l1, l0))
 
 
 @pytest.mark.parametrize("prec", ["fp16x3", "fp16", "bf16"])

@@ -70,6 +70,9 @@ def _pmc(path):
 
 def _traffic(rows, needle):
     hits = [r for k, r in rows.items() if needle in k and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg")]
+    # the benchmarked instantiation: bf16 (mangled "IDF16b" / demangled "__bf16"), not the fp16 / split-pair ones the same run times
+    bf = [r for r in hits if ("IDF16b" in r["Kernel"] or "__bf16" in r["Kernel"]) and "Lb1" not in r["Kernel"] and ", true>" not in r["Kernel"]]
+    hits = bf or hits
     if not hits:
         return None, None
     r = max(hits, key=lambda r: float(r["FETCH_SIZE_avg"]))  # (wsi: the level-0 launch is the largest instantiation)
@@ -81,8 +84,8 @@ bench_rows, wsi_rows = _pmc(os.path.join(out, "pmc_per_kernel.csv")), _pmc(os.pa
 tj = {"_doc": "HBM bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, HIPAC_LANES=1; "
               "tools/collect_profiles.sh + tools/summarize_profiles.py), counter unit KB, FETCH_SIZE doubled (gfx950 reports half "
               "of the bytes of wide streaming reads), WRITE_SIZE as is; per-kernel averages beside this file in pmc_per_kernel*.csv"}
-for key, needle, rows in (("stem7x7+pool", "stem_pool_strip2_kernel", bench_rows), ("l1b0", "block_c64_kernel", bench_rows),
-                          ("l1b1", "block_c64_kernel", bench_rows), ("wsi_level0_planes", "planes_kernel", wsi_rows)):
+for key, needle, rows in (("stem7x7+pool", "stem_pool_strip2_kernel", bench_rows), ("l1b0", "_c64_kernel", bench_rows),
+                          ("l1b1", "_c64_kernel", bench_rows), ("wsi_level0_planes", "planes_kernel", wsi_rows)):
     v, d = _traffic(rows, needle)
     if v is not None:
         tj[key], tj[key + "_detail"] = v, d
