@@ -30,13 +30,7 @@ namespace hipac {
 #define HIPAC_B16_NSLOT 4  // weight ring: 8 KB slots
 #endif
 
-// tap order inside a half-chunk.  Stride 1: row-major.  Stride 2: by plane -- (1,1): taps (0,0) (0,2) (2,0) (2,2); (0,1): (1,0)
-// (1,2); (1,0): (0,1) (2,1); (0,0): (1,1) -- so that a plane's taps are consecutive and the band changes at positions 0, 4, 6, 8.
-// (Arithmetic on a packed constant, not a table: a table indexed at run time becomes a scalar LOAD, and scalar loads share the
-// lgkmcnt counter the written-out MFMA stream counts its LDS reads with.)
-template <int STRIDE> __host__ __device__ constexpr int b16_tap(int k) { return STRIDE == 1 ? k : (int)((0x471538620ull >> (4 * k)) & 15); }
-template <int STRIDE> __host__ __device__ constexpr int b16_kh(int k) { return b16_tap<STRIDE>(k) / 3; }
-template <int STRIDE> __host__ __device__ constexpr int b16_kw(int k) { return b16_tap<STRIDE>(k) % 3; }
+// (b16_tap / b16_kh / b16_kw: the tap order inside a half-chunk, defined in halo16.h, which shares it)
 template <int STRIDE> __host__ __device__ constexpr bool b16_seg_start(int k) { return STRIDE == 1 ? k == 0 : (k == 0 || k == 4 || k == 6 || k == 8); }
 template <int STRIDE> __host__ __device__ constexpr int b16_next_start(int k) {  // position of the next segment's first tap (9: next half-chunk)
   if (STRIDE == 1) return 9;

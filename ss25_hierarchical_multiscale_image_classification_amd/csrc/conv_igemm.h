@@ -2653,6 +2653,14 @@ constexpr bool halo_pool_available() { return HIPAC_HALO_MF16 && HIPAC_H16_DIREC
 template <int COUT> struct TileCfg { static constexpr int BM = HIPAC_BM_A, BN = (COUT % HIPAC_BN_A == 0 ? HIPAC_BN_A : 128), NSTAGE = HIPAC_NSTAGE_A; };
 template <> struct TileCfg<64> { static constexpr int BM = HIPAC_BM_64, BN = 64, NSTAGE = HIPAC_NSTAGE_B; };
 
+#ifndef HIPAC_S2_HALO16
+#define HIPAC_S2_HALO16 1  // the 3x3 / stride 2 entry convs on halo16's stride-2 form (whole-pixel plane bands); 0: band16.h
+#endif
+#ifndef HIPAC_S2_HALO16_MAXCIN
+#define HIPAC_S2_HALO16_MAXCIN 512  // ... up to this many input channels.  Above it: band16.h's double-buffered half-chunk bands --
+                                    // measured EQUAL for layers 3-4 (114 / 102 vs 116 / 103 ns per patch: what the hidden band round trips
+                                    // gain, the 64-byte rows and the doubled per-tap address work cost), slower for layer2 (165 vs 183)
+#endif
 #ifndef HIPAC_BLK16
 #define HIPAC_BLK16 1  // the fused layer1 block on v_mfma_f32_16x16x32 (block16_c64.h); 0: the 32x32x16 form (block_c64.h)
 #endif
@@ -2724,6 +2732,23 @@ static int launch_conv(const void* in, const ConvW& w, const void* resid, void* 
                        n_mtiles, zero_page, (const T*)nullptr);
   } else if constexpr (HIPAC_BAND16_S1 && HIPAC_HALO_MF16 && KS == 3 && STRIDE == 1 && !SPLIT && sizeof(T) == 2 && !OUTF32 && COUT % 128 == 0 && HI == WI) {
     return launch_band16<T, CIN, COUT, HI, 1, RELU, RESID, 0>(in, w, resid, out, n, s);
+  } else if constexpr (HIPAC_S2_HALO16 && HIPAC_BAND16 && HIPAC_HALO_MF16 && KS == 3 && STRIDE == 2 && !SPLIT && sizeof(T) == 2 && !OUTF32 && !RESID && CIN <= HIPAC_S2_HALO16_MAXCIN &&
+                       COUT % 128 == 0 && HI == WI) {
+    // the entry convs of layers 2-4 on halo16's stride-2 form: four parity-plane bands per 64-channel chunk
+    constexpr int HO = HI / 2, BM = 256, BN = 128, NSW = 2;
+    constexpr int LDS = halo_band_pieces(HO, BM) * 1024 + NSW * BN * 128;
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    auto kern = conv3x3_halo16_kernel<T, CIN, COUT, HO, HO, BM, BN, NSW, RELU, false, false, 0, false, true>;
+    static bool attr_done[kMaxDevices] = {};
+    if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+    const int Mo = n * HO * HO;
+    const int n_mtiles = (Mo + BM - 1) / BM;
+    const int mt8 = (n_mtiles + 7) / 8 * 8;
+    const int n_vtiles = mt8 * (COUT / BN);
+    dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const T*)in, (const T*)w.w, w.bias, (const T*)nullptr, out, Mo, n, n_mtiles, zero_page,
+                       (const T*)nullptr);
+    return (int)hipGetLastError();
   } else if constexpr (HIPAC_BAND16 && HIPAC_HALO_MF16 && KS == 3 && STRIDE == 2 && !SPLIT && sizeof(T) == 2 && !OUTF32 && !RESID && COUT % 128 == 0 && HI == WI) {
     return launch_band16<T, CIN, COUT, HI / 2, 2, RELU, false, 0>(in, w, nullptr, out, n, s);
   } else if constexpr (HIPAC_USE_HALO && KS == 3 && STRIDE == 1) {

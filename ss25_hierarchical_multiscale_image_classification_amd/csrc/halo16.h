@@ -82,6 +82,13 @@ __device__ __forceinline__ void wait_lgkmcnt() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
 }
 
+// tap order inside a half-chunk.  Stride 1: row-major.  Stride 2: by plane -- (1,1): taps (0,0) (0,2) (2,0) (2,2); (0,1): (1,0)
+// (1,2); (1,0): (0,1) (2,1); (0,0): (1,1) -- so that a plane's taps are consecutive and the band changes at positions 0, 4, 6, 8.
+// (Arithmetic on a packed constant, not a table: a table indexed at run time becomes a scalar LOAD, and scalar loads share the
+// lgkmcnt counter the written-out MFMA stream counts its LDS reads with.)
+template <int STRIDE> __host__ __device__ constexpr int b16_tap(int k) { return STRIDE == 1 ? k : (int)((0x471538620ull >> (4 * k)) & 15); }
+template <int STRIDE> __host__ __device__ constexpr int b16_kh(int k) { return b16_tap<STRIDE>(k) / 3; }
+template <int STRIDE> __host__ __device__ constexpr int b16_kw(int k) { return b16_tap<STRIDE>(k) % 3; }
 __host__ __device__ constexpr int perm16(int n) { return n < 4 ? 2 * n : (n < 12 ? 2 * n - 7 : 2 * n - 16); }
 __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) / 2 : (j < 8 ? j / 2 : j / 2 + 8); }
 
@@ -133,7 +140,7 @@ __device__ inline float row16_sum(float v) { return v; }
 #endif
 
 template <typename T, int CIN, int COUT, int H, int W, int BM, int BN, int NSW, bool RELU, bool RESID, bool OUTF32, int PCIN = 0,
-          bool POOL = false>
+          bool POOL = false, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                                 const float* __restrict__ bias, const T* __restrict__ resid,
                                                                 void* __restrict__ outp, int M, int n_img, int n_mtiles,
@@ -158,6 +165,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   constexpr bool RESID_MFMA = RESID && HIPAC_H16_RESID_MFMA && HIPAC_H16_ASM && HIPAC_H16_DIRECT;  // see "the residual, added on the matrix pipe"
   constexpr bool EPI_RESID = RESID && !RESID_MFMA;  // the epilogue loads and adds the residual itself
   static_assert(sizeof(T) == 2, "16-bit operands");
+  // S2: a 3x3 / STRIDE 2 conv (H x W = the OUTPUT map, the input is 2H x 2W): the nine taps fall on the four parity planes of the
+  // input (band16.h has the geometry), each a stride-1 problem on the output grid, so a K step is unchanged and only the
+  // band differs -- per 64-channel chunk FOUR bands (planes (1,1), (0,1), (1,0), (0,0) with 4 / 2 / 2 / 1 taps), gathered
+  // pixel by pixel (full 128-byte rows), one after the other into the single band buffer.  Each band's DMA round trip is
+  // exposed, which is why layers 3-4 use band16.h's double-buffered half-chunk bands instead; for CIN = 64 (layer2's entry)
+  // a half-chunk band is a HALF cache line per pixel and the DMA engine, not the exposure, bounds that kernel.
+  static_assert(!S2 || (PCIN == 0 && !RESID && !POOL && !OUTF32 && HIPAC_H16_DIRECT && HIPAC_H16_ASM), "stride-2 form: plain entry conv");
   static_assert(!POOL || (OUTF32 && RELU && HIPAC_H16_DIRECT && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16),
                 "pooled epilogue: the fp32 form of the direct epilogue, maps of more than 16 pixels");
   static_assert(PCIN % 64 == 0 && (PCIN == 0 || !RESID), "folded projection replaces the residual input");
@@ -194,8 +208,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   // sent out of range explicitly, and a lane's offset inside a piece does not depend on the piece -- a wave's pieces
   // p = wave, wave + 4, ... all have p's parity, so the swizzle term (q >> 1) & 7 = (4 p + (prow >> 1)) & 7 is a per-lane
   // constant: one add per piece.  (Slots past the band's end receive whatever pixels follow; no stored result reads them.)
-  const rsrc_t a_rsrc = make_rsrc(in_b, M * CIN * 2);
+  const rsrc_t a_rsrc = make_rsrc(in_b, S2 ? n_img * (4 * H * W * CIN * 2) : M * CIN * 2);
   const int a_lane = (prow * CIN + (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 8) * 2;
+  // S2: per-lane input pixel (2 r, 2 c) of every band piece this wave issues (slot q = 8 p + prow holds output-grid pixel
+  // m0 - W - 3 + q), -1 where the slot is a zero slot or lies outside the batch; made once per tile
+  constexpr int NPB = S2 ? (A_PIECES + 3) / 4 : 1;
+  int b_pix[NPB];
+  auto plane_offsets = [&](int m0_) {
+    if constexpr (S2) {
+#pragma unroll
+      for (int k = 0; k < NPB; ++k) {
+        const int q = 8 * (wave + 4 * k) + prow;
+        const int u = m0_ - W - 3 + q;
+        const int b = u / (H * W), rem = u - b * (H * W), r = rem / W, c = rem - r * W;
+        b_pix[k] = (q >= 2 && u >= 0 && u < M) ? (b * (2 * H) + 2 * r) * (2 * W) + 2 * c : -1;
+      }
+    }
+  };
+  // band of the plane of tap position k (band16.h's order: positions 0-3 plane (1,1), 4-5 (0,1), 6-7 (1,0), 8 (0,0)), chunk cc
+  auto issue_plane_band = [&](int k, int cc) {
+    if constexpr (S2) {
+      const int py = k < 4 ? 1 : (k < 6 ? 0 : (k < 8 ? 1 : 0)), px = k < 6 ? 1 : 0;
+      const int pofs = (py * 2 * W + px) * CIN * 2 + cc * 128 + (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 16;
+#pragma unroll
+      for (int kk = 0; kk < NPB; ++kk) {
+        const int p = wave + 4 * kk;
+        if (p < A_PIECES) buffer_load_lds16(a_rsrc, Abuf + p * 1024, b_pix[kk] < 0 ? (int)0x80000000 : b_pix[kk] * (CIN * 2) + pofs, 0);
+      }
+    }
+  };
   auto issue_band_of = [&](int m0_, int cc) {
     const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
     const int npieces_ = (mlast_ - m0_ + 1 + 2 * W + 2 + 2 + 7) >> 3;
@@ -249,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       return;
     }
     const int cc = step / 9, tap = step - cc * 9;
-    const int kofs_bytes = (tap * CIN + cc * 64) * 2;
+    const int kofs_bytes = ((S2 ? b16_tap<2>(tap) : tap) * CIN + cc * 64) * 2;  // (S2: `tap` is the position in plane order)
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
@@ -289,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     int y = rem / W, x = rem - y * W;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+      epk |= (unsigned)((x == 0 ? 1 : 0) | (!S2 && x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (!S2 && y == H - 1 ? 8 : 0)) << (4 * i);
       x += 16 % W, y += 16 / W;
       if (x >= W) x -= W, y += 1;
       if (y >= H) y -= H;
@@ -398,7 +439,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   unsigned long long t_first = 0;
 #endif
   int s = 0;  // K step counter
-  if (first_tile) issue_band_of(m0, 0);
+  if constexpr (S2) plane_offsets(m0);
+  if (first_tile) {
+    if constexpr (S2) issue_plane_band(0, 0);
+    else issue_band_of(m0, 0);
+  }
   if (!DIRECT || first_tile) {  // (DIRECT: the previous tile's epilogue has requested them)
 #pragma unroll
     for (int pstep = 0; pstep < NSW - 1; ++pstep)
@@ -407,10 +452,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   for (int cc = 0; cc < CC; ++cc) {
     if (cc > 0) {
       __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous chunk's band
-      issue_band_of(m0, cc);
+      if constexpr (S2) issue_plane_band(0, cc);
+      else issue_band_of(m0, cc);
     }
 #pragma unroll HIPAC_HALO_TAP_UNROLL
     for (int tap = 0; tap < 9; ++tap, ++s) {
+      if (S2 && (tap == 4 || tap == 6 || tap == 8)) {  // the next plane's band (its round trip is exposed: the wait below drains it)
+        __builtin_amdgcn_s_barrier();
+        issue_plane_band(tap, cc);
+      }
       // W(s) must have landed; the band too at tap 0 (it was issued AFTER W(s+1..), so drain everything)
       if (NSW == 3 && tap != 0 && s + 1 < NSTEP) wait_vmcnt<WPW>();
       else if (DIRECT && s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the epilogue's stores
@@ -422,10 +472,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
         __builtin_amdgcn_s_waitcnt(0xC07F);
       }
 #endif
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const int toff = (kh - 1) * W + kw - 1;
+      const int tap_w = S2 ? b16_tap<2>(tap) : tap;  // the tap's index in the weights
+      const int kh = tap_w / 3, kw = tap_w - kh * 3;
+      const int toff = S2 ? (kh == 0 ? -W : 0) + (kw == 0 ? -1 : 0) : (kh - 1) * W + kw - 1;
       const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
-      const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (kh == 2 ? 8u : 0u)) * 0x11111111u;
+      const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (!S2 && kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (!S2 && kh == 2 ? 8u : 0u)) * 0x11111111u;
       // out-of-image taps read a zero pixel: slot 0 or 1 by the parity of the slot the lane would have read, at the chunk
       // position its swizzle selects -- the same 16-byte bank group as the in-image address.  (qt + 16 i) has the parity and
       // the swizzle of qt: one swizzle term per tap.
@@ -559,7 +610,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       const int vn = vb + gridDim.x;
       const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
       if (mtn < n_mtiles) {
-        issue_band_of(mtn * BM, 0);
+        if constexpr (S2) {
+          plane_offsets(mtn * BM);
+          issue_plane_band(0, 0);
+        } else {
+          issue_band_of(mtn * BM, 0);
+        }
         const int dn = (((vn >> 3) % NTILES_N) * BN - n0) * KTOT * 2;  // the next tile's weight rows relative to this one's
 #pragma unroll
         for (int i = 0; i < WPW; ++i) w_off[i] += dn;

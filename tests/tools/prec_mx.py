@@ -53,12 +53,21 @@ def mx_quant(v, fmt):
     return out[:, :c] if pad else out
 
 
+def const_quant(v, shift):
+    """e4m3 with ONE constant power-of-two scale for the whole tensor (no block scales): fp8(v * 2^shift) / 2^shift."""
+    return (v * 2.0 ** shift).clamp(-448, 448).to(torch.float8_e4m3fn).float() / 2.0 ** shift
+
+
 def conv3(x, w, b, fmt, mode, **kw):
     """One convolution in the emulated arithmetic.  mode: 'x3' three products, 'x1' single fp16 product."""
     xh, xl = pair(x)
     wh, wl = pair(w)
     y = F.conv2d(xh.double(), wh.double(), None, **kw)
-    if mode == 'x3':
+    if mode == 'x3' and fmt == 'e4m3const':
+        # hi parts as they are, lo parts times 2^11 (|lo| <= 2^-11 |hi|), every tensor with the same constants
+        y = y + F.conv2d(const_quant(xl, 11).double(), const_quant(wh, 4).double(), None, **kw) \
+              + F.conv2d(const_quant(xh, 0).double(), const_quant(wl, 15).double(), None, **kw)
+    elif mode == 'x3':
         wq = lambda t: mx_quant(t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]), fmt).reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[1]).permute(0, 3, 1, 2)
         aq = lambda t: mx_quant(t, fmt)
         y = y + F.conv2d(aq(xl).double(), wq(wh).double(), None, **kw) + F.conv2d(aq(xh).double(), wq(wl).double(), None, **kw)
@@ -95,7 +104,8 @@ lut = torch.from_numpy(T.normalize_lut())
 x = torch.stack([lut[c][u8[..., c].long()] for c in range(3)], dim=1)
 with torch.no_grad():
     rf, rl = R.resnet18_forward(x, sd)
-    for nm, fmt, mode in [('fp16x3 (exact cross terms)', None, 'x3'), ('cross terms MXFP8 e4m3', 'e4m3', 'x3'),
+    for nm, fmt, mode in [('cross terms e4m3, constant scales', 'e4m3const', 'x3'),
+                          ('fp16x3 (exact cross terms)', None, 'x3'), ('cross terms MXFP8 e4m3', 'e4m3', 'x3'),
                           ('cross terms MXFP6 e2m3', 'e2m3', 'x3'), ('single fp16 product', None, 'x1')]:
         f, l = sim(x, sd, fmt, mode)
         print(f'{nm:30s} feats {rel(f, rf):.2e} logits {rel(l, rl):.2e} labels equal {bool((l.argmax(1) == rl.argmax(1)).all())}', flush=True)
