@@ -22,6 +22,10 @@
 
 namespace hipac {
 
+#ifndef HIPAC_BLK16_AHEAD
+#define HIPAC_BLK16_AHEAD 1
+#endif
+
 // one step of a wave: rows 0 .. 2 NP - 1 (NP pairs of rows; pair p's 4-row window starts at lb[p][.]), all 9 taps x 64 channels.
 // lb[p][kw]: LDS byte address of (window row 0, column perm16(n) + kw, chunk g swizzled) of pair p.
 template <typename T, int NP, int PITCH>
@@ -38,24 +42,26 @@ __device__ __forceinline__ void c64_strip16_mfma(const typename Elem<T>::frag (&
   }
   // the bias values came through LDS reads hipcc waits for itself; from here on the LDS reads are counted by hand
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  frag fr[2][NR];
+  constexpr int AH = HIPAC_BLK16_AHEAD;  // groups of NR fragment reads in flight ahead of the group whose MFMAs are being issued
+  frag fr[AH + 1][NR];
   // group s = (tap, k32 step): row i of pair p reads (lb[p][kw] ^ (kk << 6)) + ((i & 1) + kh) * PITCH
   auto rd = [&](auto S, auto I) {
     constexpr int s = decltype(S)::value, i = decltype(I)::value;
     constexpr int tap = s >> 1, kk = s & 1, kh = tap / 3, kw = tap % 3;
-    lds_read16<((i & 1) + kh) * PITCH>(fr[s & 1][i], (unsigned)(lb[i >> 1][kw] ^ (kk << 6)));
+    lds_read16<((i & 1) + kh) * PITCH>(fr[s % (AH + 1)][i], (unsigned)(lb[i >> 1][kw] ^ (kk << 6)));
   };
   __builtin_amdgcn_s_setprio(1);
-  static_for<NR>([&](auto I) { rd(std::integral_constant<int, 0>{}, I); });
+  static_for<AH>([&](auto S) { static_for<NR>([&](auto I) { rd(S, I); }); });
   static_for<18>([&](auto S) {
     constexpr int s = decltype(S)::value, tap = s >> 1, kk = s & 1;
     static_for<NR>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      if constexpr (s + 1 < 18) rd(std::integral_constant<int, s + 1>{}, I);
-      // outstanding behind fragment (s, i): (s, i+1 ..) and (s+1, 0 .. i) = NR reads; the last group: NR - 1 - i
-      wait_lgkmcnt<(s + 1 < 18) ? NR : NR - 1 - i>();
-      Asm16<T>::mfma(acc[i][0], wreg[tap][kk][0], fr[s & 1][i]);
-      Asm16<T>::mfma(acc[i][1], wreg[tap][kk][1], fr[s & 1][i]);
+      if constexpr (s + AH < 18) rd(std::integral_constant<int, s + AH>{}, I);
+      // outstanding behind fragment (s, i): the rest of group s, the groups s+1 .. s+AH-1 that exist, and rows 0 .. i of group s+AH
+      constexpr int full = (18 - 1 - s < AH - 1 ? 18 - 1 - s : AH - 1);  // whole groups behind it
+      wait_lgkmcnt<(NR - 1 - i) + full * NR + (s + AH < 18 ? i + 1 : 0)>();
+      Asm16<T>::mfma(acc[i][0], wreg[tap][kk][0], fr[s % (AH + 1)][i]);
+      Asm16<T>::mfma(acc[i][1], wreg[tap][kk][1], fr[s % (AH + 1)][i]);
     });
   });
   __builtin_amdgcn_s_setprio(0);
