@@ -67,12 +67,12 @@ for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
 assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 
-KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block16_c64_kernel" if L1_FUSED else "conv3x3_c64_kernel", "l2b0c1": "conv3x3_band16_kernel",
-                "l3b0c1": "conv3x3_band16_kernel", "l4b0c1": "conv3x3_band16_kernel", "l4proj": "conv_glds_kernel"}
+KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block16_c64_kernel" if L1_FUSED else "conv3x3_c64_kernel", "l4proj": "conv_glds_kernel"}
 
 
 def kernel_of(op: str) -> str:
-    # the stride-1 3x3 convs of layers 2-4: the halo kernel on v_mfma_f32_16x16x32 (csrc/halo16.h) for bf16 / fp16
+    # every 3x3 conv of layers 2-4 (stride 1, and the stride-2 entry convs as four plane bands): the halo kernel on
+    # v_mfma_f32_16x16x32 (csrc/halo16.h) for bf16 / fp16
     return KERNEL_OF_OP.get(op) or KERNEL_OF_OP.get(op[:2]) or "conv3x3_halo16_kernel"
 
 
