@@ -103,8 +103,18 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
 #define HIPAC_H16_RESID_MFMA 1  // 1: the residual is added by the matrix pipe (identity "weights" over the residual tile brought
                                 // into LDS by DMA, after the last tap); 0: loaded into registers and added in the epilogue
 #endif
+#ifndef HIPAC_H16_EPI_PRIO
+#define HIPAC_H16_EPI_PRIO 0  // s_setprio level of the epilogue's store loop (the K loop runs at 1)
+#endif
+#ifndef HIPAC_H16_STAGE16
+#define HIPAC_H16_STAGE16 0  // 1: 16-bit outputs leave through a 4 KB LDS transpose per wave as whole cache lines (see STAGE16; measured equal)
+#endif
+#ifndef HIPAC_H16_XCD_CHUNKS
+#define HIPAC_H16_XCD_CHUNKS 1  // 1: M-tiles dealt to the XCDs in contiguous runs (neighbouring tiles share W + 1 band pixels: L2 hits;
+                                // entry convs -2..-3 %, the rest +-0), 0: round-robin
+#endif
 #ifndef HIPAC_H16_ABL
-#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects, 32 no stores
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -255,7 +265,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   bool prev_full = false;
   for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
   const int xcd = vb & 7, slot = vb >> 3;
+#if HIPAC_H16_XCD_CHUNKS
+  // every XCD takes a contiguous run of M-tiles: neighbouring tiles share W + 1 band pixels, which then hit that XCD's L2
+  const int mt_q = (n_mtiles + 7) >> 3;
+  const int mt = (slot / NTILES_N) < mt_q ? xcd * mt_q + slot / NTILES_N : n_mtiles;
+#else
   const int mt = (slot / NTILES_N) * 8 + xcd;
+#endif
   const int nt = slot % NTILES_N;
   if (mt >= n_mtiles) break;  // mt grows with vb on a fixed XCD: nothing valid follows
   const int m0 = mt * BM, n0 = nt * BN;
@@ -582,6 +598,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + n0 + wn * WTN + 16 * j + 4 * g);
     const int c_lane = n0 + wn * WTN + 16 * (g & 1) + 8 * (g >> 1);  // + 32 jp: first of the 8 channels this lane stores
+    // STAGE16: the 16-byte items (one pixel each, neighbouring lanes on DIFFERENT pixels: every store instruction touches 16
+    // half lines and costs the address coalescer 4x the cycles of a contiguous one -- removing the stores altogether made the
+    // layer2 / layer3 convs 16-22 % faster, most of it the OTHER workgroup's weight DMA queueing behind these bursts) go through
+    // LDS once more, 32 pixels at a time, and leave as whole 128-byte lines
+    constexpr bool STAGE16 = HIPAC_H16_STAGE16 && !OUTF32 && NSW == 2 && WTN == 64;
+    unsigned char* const Sw16 = Wbuf + W_BYTES + wave * 4096;
     // ALL of the tile's residual loads are requested up front (the K loop's fragment registers are free now): vector-memory
     // operations retire in order, so a load requested later would queue behind the next tile's band and weight DMA below
     u32x4 rq[MT][EPI_RESID && !OUTF32 ? NT / 2 : 1];
@@ -608,7 +630,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     {
       // the next tile's first band chunk and first weight tile(s) land behind this epilogue
       const int vn = vb + gridDim.x;
+#if HIPAC_H16_XCD_CHUNKS
+      const int mtn = ((vn >> 3) / NTILES_N) < ((n_mtiles + 7) >> 3) ? (vn & 7) * ((n_mtiles + 7) >> 3) + (vn >> 3) / NTILES_N : n_mtiles;
+#else
       const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
+#endif
       if (mtn < n_mtiles) {
         if constexpr (S2) {
           plane_offsets(mtn * BM);
@@ -625,6 +651,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       }
     }
     HALO_STAMP(t_pref);
+#if HIPAC_H16_EPI_PRIO
+    __builtin_amdgcn_s_setprio(HIPAC_H16_EPI_PRIO);
+#endif
     // pooled epilogue state: S[..][0] = sums of the values rounded to the grid 2^-10, S[..][1] = sums of the remainders rounded
     // to the grid 2^-29, for the image the walk over the wave's pixels is in
     [[maybe_unused]] f32x4 poolS[NT][2];
@@ -740,9 +769,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
           }
           permlane16_swap(P[0][0], P[1][0]);
           permlane16_swap(P[0][1], P[1][1]);
-          if (m < M)
+          if constexpr (STAGE16) {
+            // through the wave's 4 KB of ring slot 1 (slot 0 is receiving the next tile's first weight tile): [32 px][128 B],
+            // 16-byte position c ^ (px & 7) -- the eight lanes a ds_write_b128 serves together are eight pixels of different
+            // px & 7 (perm16), i.e. eight different positions = all 32 banks
+            const int spx = (i & 1) * 16 + pn;
+            const int sch = 4 * jp + 2 * (g & 1) + (g >> 1);  // the 16-byte chunk of the wave's 128 bytes this lane holds
+            *reinterpret_cast<u32x4*>(Sw16 + spx * 128 + ((sch ^ (spx & 7)) << 4)) = u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
+          } else if ((HIPAC_H16_ABL & 32) ? m < 0 : m < M)  // (ablation 32: no stores)
             *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + c_lane + 32 * jp) =
                 u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
+        }
+        if constexpr (STAGE16 && (i & 1)) {
+          // the 32-pixel group is staged: out as whole 128-byte lines -- 8 lanes per pixel, 16 bytes each
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int spx = (lane >> 3) + 8 * k, sch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(Sw16 + spx * 128 + ((sch ^ (spx & 7)) << 4));
+            const int ms = m0 + wm * WPX + (i >> 1) * 32 + spx;
+            if ((HIPAC_H16_ABL & 32) ? ms < 0 : ms < M)
+              *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(outp) + (size_t)ms * COUT + n0 + wn * WTN + sch * 8) = v;
+          }
         }
       }
     });
@@ -759,6 +806,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
       atomicAdd(&g_halo_stamps[7], t_setup - t_start);
     }
 #endif
+#if HIPAC_H16_EPI_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     prev_full = !POOL && (m0 + BM <= M);  // (POOL: the number of stores depends on the images the tile meets)
     continue;  // next tile
   }
@@ -773,7 +823,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
   {
     // prefetch the next tile's first band chunk; it lands behind this epilogue
     const int vn = vb + gridDim.x;
+#if HIPAC_H16_XCD_CHUNKS
+    const int mtn = ((vn >> 3) / NTILES_N) < ((n_mtiles + 7) >> 3) ? (vn & 7) * ((n_mtiles + 7) >> 3) + (vn >> 3) / NTILES_N : n_mtiles;
+#else
     const int mtn = ((vn >> 3) / NTILES_N) * 8 + (vn & 7);
+#endif
     if (mtn < n_mtiles) issue_band_of(mtn * BM, 0);
   }
   HALO_STAMP(t_pref);
