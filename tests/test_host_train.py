@@ -129,5 +129,5 @@ def test_bench_launcher_builds_one_process_per_rank():
     args = bench.build_parser().parse_args(["--gpus", "2", "--_child"])
     assert args.gpus == 2 and args._child and args.workload == "resnet" and args.steps == 8 and args.warmup == 2
     assert bench.host_threads() >= 1
-    assert bench.kernel_of("l1b0") == "block_c64_kernel" and bench.kernel_of("l3b1c1") == "conv3x3_halo_kernel"
+    assert bench.kernel_of("l1b0") == "block16_c64_kernel" and bench.kernel_of("l3b1c1") == "conv3x3_halo16_kernel"
     assert [n for n, _ in bench.OPS][2:6] == ["l1b0", "(fused)", "l1b1", "(fused)"]  # a layer1 BasicBlock is one launch
