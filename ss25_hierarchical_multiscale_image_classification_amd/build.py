@@ -23,8 +23,8 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / os.environ.get("HIPAC_OBJ_DIR", "build")
 LIB = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")
 SOURCES = ["hipac_capi.hip", "preprocess.hip", "level_planes.hip", "mil.hip", "ntxent.hip", "conv_bf16.hip", "conv_f16.hip",
-           "conv_f32.hip", "conv_f16x3.hip", "train.hip", "train_amp.hip", "augment.hip", "jpeg_decode.hip"]
-HEADERS = ["common.h", "conv_igemm.h", "block_c64.h", "halo16.h", "band16.h", "block16_c64.h", "train_common.h", "../../include/hipac.h"]
+           "conv_f32.hip", "conv_f16x3.hip", "conv_f16q8.hip", "train.hip", "train_amp.hip", "augment.hip", "jpeg_decode.hip"]
+HEADERS = ["common.h", "conv_igemm.h", "block_c64.h", "halo16.h", "halo16x2.h", "e4m3.h", "band16.h", "block16_c64.h", "train_common.h", "../../include/hipac.h"]
 ARCH = "gfx950"
 # -ffp-contract=off: the host-side Pillow coefficient restatement must round every
 # double operation separately (no fused multiply-add), see preprocess.hip.

@@ -19,16 +19,16 @@ import torch
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / os.environ.get("HIPAC_LIB_NAME", "libhipac_hip.so")  # override: A/B builds of the same ABI
 
-PREC_BF16, PREC_FP16, PREC_FP32, PREC_FP16X3 = 0, 1, 2, 3
+PREC_BF16, PREC_FP16, PREC_FP32, PREC_FP16X3, PREC_FP16Q8 = 0, 1, 2, 3, 4
 IN_NCHW_F32, IN_NHWC4_PAD, IN_U8_HWC = 0, 1, 2
 OUT_NCHW_F32, OUT_NHWC4_PAD_BF16, OUT_NHWC4_PAD_FP16, OUT_U8_HWC = 0, 1, 2, 3
 PATCH, PAD_H, PAD_W = 224, 230, 232
-ABI_VERSION = 7  # include/hipac.h HIPAC_ABI_VERSION this binding was written against
+ABI_VERSION = 8  # include/hipac.h HIPAC_ABI_VERSION this binding was written against
 
 # "fp16x3" is the parity mode (fp16 (hi, lo) pairs, three MFMA products per term: the reference's fp32 results to 1e-3);
 # "fp32" the debugging reference: fp32 storage and the exact f32 MFMA (about 1/16 of the bf16 rate)
-PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16, "fp32": PREC_FP32, "fp16x3": PREC_FP16X3}
-TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16, PREC_FP32: torch.float32, PREC_FP16X3: torch.float32}
+PRECISIONS = {"bf16": PREC_BF16, "fp16": PREC_FP16, "fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16q8": PREC_FP16Q8}
+TORCH_DTYPE = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16, PREC_FP32: torch.float32, PREC_FP16X3: torch.float32, PREC_FP16Q8: torch.float32}
 
 
 class HipacError(RuntimeError):

@@ -122,6 +122,7 @@ struct Plan {
   int pool_head;  // 1 = the last conv's epilogue reduces the 7x7 map per image (partial sums in `part`, head_pool_kernel
                   // finishes), 0 = it stores the fp32 map blk[7] and head_kernel reads it (HIPAC_POOL_HEAD=0; fp32 / fp16x3)
   size_t part;    // float[ceil(gc * 49 / 256)][2][kPoolSlots = 7][2][512] partial sums of the global average pool
+  size_t q8;      // precision fp16q8: the e4m3 tensor [pixel][C / 64][lo8: 64 | hi8: 64] of the pair tensor at offset o is at q8 + o / 2
   // early, sized for bc images
   size_t xin;     // T[bc,230,232,4]
   size_t stem;    // T[bc,112,112,64]
@@ -149,6 +150,8 @@ int run_trunk_f16(const Net& net, const Plan& p, char* ws, const void* xin, int 
 int run_trunk_f32(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                   hipStream_t s, int first, int last);
 int run_trunk_f16x3(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
+                    hipStream_t s, int first, int last);
+int run_trunk_f16q8(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                     hipStream_t s, int first, int last);
 int launch_u8_to_nhwc4_f32(const unsigned char* x, const float* lut, float* out, int n, hipStream_t s);
 

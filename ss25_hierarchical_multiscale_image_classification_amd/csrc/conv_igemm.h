@@ -1267,6 +1267,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const T* __rest
 
 }  // namespace hipac
 #include "halo16.h"
+#include "halo16x2.h"
 #include "band16.h"
 namespace hipac {
 
@@ -2937,6 +2938,29 @@ static int launch_down(const void* in, const ConvW& w, const ConvW& wp, void* ou
     }                            \
   } while (0)
 
+// precision fp16q8 (halo16x2.h): the q8 tensor of the pair tensor at workspace offset o lives at Plan::q8 + o / 2
+struct Q8Map {
+  char* ws;
+  size_t q8;
+  void* of(const void* pairs) const { return ws + q8 + (size_t)((const char*)pairs - ws) / 2; }
+};
+template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false>
+static int launch_halo16x2(const void* in, const void* in_q, const ConvW& w, const void* resid, void* out, void* out_q, int n, hipStream_t s) {
+  constexpr int BM = 256, BN = COUT % 128 == 0 ? 128 : 64;
+  constexpr int LDS = halo_band_pieces(HW, BM) * 1024 + 2 * BN * 128;
+  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32>;
+  static bool attr_done[kMaxDevices] = {};
+  if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
+  const int M = n * HW * HW;
+  const int n_mtiles = (M + BM - 1) / BM;
+  const int mt8 = (n_mtiles + 7) / 8 * 8;
+  const int n_vtiles = mt8 * (COUT / BN);
+  dim3 grid(n_vtiles < HIPAC_HALO_GRID ? n_vtiles : HIPAC_HALO_GRID);  // persistent; both are multiples of 8
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const _Float16*)in, (const unsigned char*)in_q, (const unsigned char*)w.w, w.bias,
+                     (const _Float16*)resid, out, (unsigned char*)out_q, M, n, n_mtiles);
+  return (int)hipGetLastError();
+}
+
 // The trunk is a fixed sequence of 21 launches ("ops"): 0 stem, 1 max-pool, then per
 // stage conv1(b0) [proj] conv2(b0) conv1(b1) conv2(b1).  `first..last` selects a
 // sub-range (whole trunk by default) so single layers can be timed / profiled.
@@ -2950,13 +2974,50 @@ struct OpRange {
 
 // One ResNet stage = two BasicBlocks.  CI/HI: input channels / spatial size,
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
-template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false>
+template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false, bool Q8 = false>
 static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
-                     hipStream_t s, OpRange& ops, bool fuse_blocks = false, void* pool_part = nullptr) {
+                     hipStream_t s, OpRange& ops, bool fuse_blocks = false, void* pool_part = nullptr, Q8Map qm = Q8Map{nullptr, 0}) {
   constexpr int HO = HI / STRIDE;
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
+  if constexpr (Q8) {
+    // precision fp16q8: the stride-1 convs on halo16x2.h (pair + q8 tensors); the stage's entry conv and projection are the
+    // fp16x3 kernels, whose pair output gets its q8 tensor from pairs_to_q8_kernel (the same op slot)
+    static_assert(SPLIT && sizeof(T) == 2, "fp16q8 extends the pair layout");
+    const void* idt = x;
+    const void* c2_in = tmp;
+    if constexpr (STRIDE == 1) {
+      if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
+    } else {
+      if constexpr (HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
+        if (ops.take()) {
+          HIPAC_TRY((launch_down<T, CI, CO, HI, true>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
+          HIPAC_TRY(launch_pairs_to_q8(tmp, qm.of(tmp), (long long)n * HO * HO, CO, s));
+        }
+        (void)ops.take();
+      } else {
+        if (ops.take()) {
+          HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false, false, true>(x, bw[0], nullptr, tmp, n, s, z)));
+          HIPAC_TRY(launch_pairs_to_q8(tmp, qm.of(tmp), (long long)n * HO * HO, CO, s));
+        }
+        if (ops.take())
+          HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false, false, true>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
+      }
+      idt = ds;
+    }
+    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, true, false>(c2_in, qm.of(c2_in), bw[1], idt, o0, qm.of(o0), n, s)));
+    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
+    if (ops.take()) {
+      if constexpr (LAST) {
+        if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
+        else HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false, true>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
+      } else {
+        HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
+      }
+    }
+    return 0;
+  }
   // second conv of the stage's second block; for the network's last one (LAST) either the fp32 map or, with `pool_part`,
   // the per-image partial sums of the global average pool (halo16.h, POOL)
   auto launch_last = [&](const void* in_, const void* resid_, void* out_) -> int {
@@ -3025,10 +3086,11 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   return 0;
 }
 
-template <typename T, bool SPLIT = false>
+template <typename T, bool SPLIT = false, bool Q8 = false>
 static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                      hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
+  const Q8Map qm{ws, p.q8};
   const int ne = n_early, nl = n_late;
   bool fused_done = false;
   if constexpr (SPLIT) {
@@ -3042,6 +3104,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
                            (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
                            ne * kPatch * kPatch * 3);
         HIPAC_TRY((int)hipGetLastError());
+        if constexpr (Q8) HIPAC_TRY(launch_pairs_to_q8(ws + p.pool, qm.of(ws + p.pool), (long long)ne * 56 * 56, 64, s));
       }
       (void)ops.take();
     } else {
@@ -3053,6 +3116,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       hipLaunchKernelGGL((maxpool3x3s2_split_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                          (const float*)(ws + p.stem), (_Float16*)(ws + p.pool), ne);
       HIPAC_TRY((int)hipGetLastError());
+      if constexpr (Q8) HIPAC_TRY(launch_pairs_to_q8(ws + p.pool, qm.of(ws + p.pool), (long long)ne * 56 * 56, 64, s));
     }
     }
     fused_done = true;
@@ -3095,12 +3159,14 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
   char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * p.esz;
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false, SPLIT>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
-                                                       p.l1_fused != 0)));
-  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops)));
-  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops,
-                                                        false, p.pool_head && halo_pool_available<T, SPLIT>() ? ws + p.part : nullptr)));
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false, SPLIT, Q8>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
+                                                           p.l1_fused != 0, nullptr, qm)));
+  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT, Q8>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops, false,
+                                                            nullptr, qm)));
+  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT, Q8>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops,
+                                                             false, nullptr, qm)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT, Q8>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops,
+                                                            false, p.pool_head && (Q8 || halo_pool_available<T, SPLIT>()) ? ws + p.part : nullptr, qm)));
   return 0;
 }
 

@@ -1,0 +1,495 @@
+// conv3x3_halo16x2_kernel: the 3x3 / stride 1 convolution of the parity mode `fp16q8` (round 4; VERDICT r3 item 3 "a parity mode
+// with cheaper cross terms").  Included by conv_igemm.h after halo16.h, whose tile, band, weight ring, lane -> pixel permutation,
+// written-out MFMA stream and direct epilogue it shares -- read that header first.
+//
+// Arithmetic.  As in fp16x3 every value is the pair hi = rn16(v), lo = rn16(v - hi) of fp16 numbers and a product is
+//     x w ~= xhi whi + (xlo whi + xhi wlo)            (the dropped xlo wlo is 2^-22 relative)
+// The first term needs the full 11-bit operands: v_mfma_f32_16x16x32_f16.  The bracket is 2^-11 of the result, so its operands
+// need ~8 significant bits for the sum to stay exact to ~2^-19: it runs on the block-scaled MX instruction
+// v_mfma_scale_f32_16x16x128_f8f6f4 with OCP e4m3 operands (measured, tools/mfma_f8_probe.hip: 2.25x the FLOP/s of the f16
+// instruction on random data under the power cap), with CONSTANT scales (tests/tools/prec_mx.py: e4m3's own exponent gives every
+// element its dynamic range; logits 5e-5 against the fp32 oracle where fp16x3 has 4e-6 and one fp16 product 1e-3):
+//     activations:  hi8 = e4m3(xhi),  lo8 = e4m3(xlo * 2^11)        weights:  whi8 = e4m3(whi * 2^4),  wlo8 = e4m3(wlo * 2^15)
+// so both cross products carry the factor 2^15, which the instruction's E8M0 scale operand (2^-15 on the weight side, 2^0 on the
+// activation side) removes on the way into the SAME fp32 accumulators the f16 products go to.
+//
+// Layout.  Activations are the fp16x3 pair tensor [pixel][hi: C | lo: C] (what the residual adds and the other kernels of the
+// mode read and write) PLUS a byte tensor q8 [pixel][C / 64][lo8: 64 | hi8: 64]: per 64-channel chunk one 128-byte row -- the
+// row format of an fp16 chunk, so the band, its swizzle and the fragment reads are those of halo16.h, and ONE K = 128 MFMA per
+// accumulator multiplies a chunk's row by the weight row [whi8: 64 | wlo8: 64]: xlo whi + xhi wlo.  (Whatever the instruction's
+// lane -> k map is, the two operands use the same one: tools/mfma_f8_probe.hip.)  Weights: per output channel and tap, per chunk
+// [hi16: 64 halves | whi8: 64 | wlo8: 64] = 256 bytes.
+//
+// K loop.  Per 64-channel chunk c: the hi band (pair tensor, chunk c of the hi plane), 9 taps of 64 f16 MFMAs; then the q8 band of
+// chunk c, 9 taps of 32 fp8 MFMAs of twice the cycles: 2 MFMA-time units per term where fp16x3 spends 3.
+#pragma once
+
+namespace hipac {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// D += 2^(sa - 127) 2^(sb - 127) A B, A / B e4m3 (cbsz = blgp = 0), K = 128
+__device__ __forceinline__ void mfma_f8_scaled(f32x4& c, const i32x8& a, const i32x8& b, int sa, int sb) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
+// four floats -> four OCP e4m3 bytes (round to nearest even, saturating at +-448: the conversion itself turns larger values into NaN)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned cvt4_e4m3(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+#else
+__device__ inline unsigned cvt4_e4m3(float, float, float, float) { return 0; }
+#endif
+constexpr float kQ8LoScale = 2048.f;  // activations' lo parts are converted as lo * 2^11
+constexpr int kQ8WhiShift = 4, kQ8WloShift = 15;  // weights: whi * 2^4, wlo * 2^15 (pack_conv_q8); 11 + 4 = 0 + 15
+constexpr int kQ8ScaleA = 127 - 15, kQ8ScaleB = 127;  // E8M0 scale operands of the MFMA
+
+// pair tensor -> q8 tensor, for the activations the mode's other kernels produce (stem + pool, the stride-2 entry convs)
+template <int UNUSED = 0>  // (a template: the header is part of several translation units)
+__global__ __launch_bounds__(256) void pairs_to_q8_kernel(const _Float16* __restrict__ in, unsigned char* __restrict__ q, long long n_items,
+                                                          int C) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;  // item = 8 channels of one pixel
+  if (gid >= n_items) return;
+  const int c8 = (int)(gid % (C / 8));
+  const long long pix = gid / (C / 8);
+  const f16x8 hi = *reinterpret_cast<const f16x8*>(in + pix * 2 * C + c8 * 8);
+  const f16x8 lo = *reinterpret_cast<const f16x8*>(in + pix * 2 * C + C + c8 * 8);
+  u32x2 h8, l8;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    h8[k] = cvt4_e4m3((float)hi[4 * k], (float)hi[4 * k + 1], (float)hi[4 * k + 2], (float)hi[4 * k + 3]);
+    l8[k] = cvt4_e4m3((float)lo[4 * k] * kQ8LoScale, (float)lo[4 * k + 1] * kQ8LoScale, (float)lo[4 * k + 2] * kQ8LoScale,
+                      (float)lo[4 * k + 3] * kQ8LoScale);
+  }
+  unsigned char* row = q + pix * 2 * C + (c8 >> 3) * 128 + (c8 & 7) * 8;
+  *reinterpret_cast<u32x2*>(row) = l8;
+  *reinterpret_cast<u32x2*>(row + 64) = h8;
+}
+static int launch_pairs_to_q8(const void* in, void* q, long long n_pix, int C, hipStream_t s) {
+  const long long items = n_pix * (C / 8);
+  hipLaunchKernelGGL(pairs_to_q8_kernel<0>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const _Float16*)in, (unsigned char*)q, items, C);
+  return (int)hipGetLastError();
+}
+
+// Q8OUT: also write the q8 tensor of the output (for a following conv of this kind).  POOL: the network's last conv -- the pooled
+// fp32 epilogue of halo16.h (partial sums in `outp`), no pair / q8 output.  OUTF32: the fp32 map float[pixel][COUT] instead of pairs.
+// BN: 128 (waves 2 x 2, each 128 px x 64 ch) or 64 (layer1: waves 4 x 1, each 64 px x 64 ch).
+template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16* __restrict__ in, const unsigned char* __restrict__ in_q,
+                                                                  const unsigned char* __restrict__ wgt, const float* __restrict__ bias,
+                                                                  const _Float16* __restrict__ resid, void* __restrict__ outp,
+                                                                  unsigned char* __restrict__ out_q, int M, int n_img, int n_mtiles) {
+  using T = _Float16;
+  using frag = f16x8;
+  constexpr int BM = 256, NSW = 2;
+  constexpr int CC = CIN / 64;                      // 64-channel chunks
+  constexpr int VC = 2 * CC;                        // bands of the K loop: chunk c's hi band (v = 2c), then its q8 band (v = 2c + 1)
+  constexpr int KROW = 9 * VC * 128;                // bytes per weight row (output channel)
+  constexpr int WN = BN / 64, WM = 4 / WN;
+  constexpr int WPX = BM / WM, MT = WPX / 16;       // 128 pixels = 8 sub-tiles per wave (BN = 64: 64 pixels = 4)
+  constexpr int WTN = BN / WN, NT = WTN / 16;       // 64 channels = 4 tiles per wave
+  constexpr int A_PIECES = halo_band_pieces(W, BM);
+  constexpr int A_BYTES = A_PIECES * 1024;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int WPW = BN / 8 / 4;
+  constexpr int NTILES_N = COUT / BN;
+  constexpr int NSTEP = 9 * VC;
+  constexpr int S_BYTES = NSW * W_BYTES;
+  static_assert((BN == 64 || BN == 128) && CIN % 64 == 0 && COUT % BN == 0 && (MT == 8 || MT == 4) && NT == 4, "tile shape");
+  static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
+  static_assert(BM + 2 * W + 4 <= A_PIECES * 8, "band slots");
+  static_assert(!POOL || (BN == 128 && RELU && !Q8OUT && !OUTF32 && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16), "pooled epilogue");
+  static_assert(!OUTF32 || !Q8OUT, "the fp32 map has no q8 tensor");
+  static_assert(!RESID || (A_BYTES >= BM * 128 && (WN == 1 || S_BYTES >= BM * 128)), "residual tile: one 64-channel chunk per region");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  unsigned char* const Abuf = ring;
+  unsigned char* const Wbuf = ring + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int pn = n16 < 4 ? 2 * n16 : (n16 < 12 ? 2 * n16 - 7 : 2 * n16 - 16);  // perm16(n16)
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const int prow = lane >> 3, dchunk = lane & 7;
+  int sc_a = kQ8ScaleA, sc_b = kQ8ScaleB;  // the MFMA's scale operands live in VGPRs
+  asm volatile("" : "+v"(sc_a), "+v"(sc_b));
+
+  // bands (halo16.h: slot q = pixel m0 - W - 3 + q, slots 0, 1 zeros, 16-byte chunk c of slot q at c ^ ((q >> 1) & 7)); the hi band
+  // comes from the pair tensor (4 CIN bytes per pixel), the q8 band from the byte tensor (2 CIN bytes per pixel)
+  const rsrc_t h_rsrc = make_rsrc(in, M * CIN * 4);
+  const rsrc_t q_rsrc = make_rsrc(in_q, M * CIN * 2);
+  const int swz16 = (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 16;
+  const int h_lane = prow * (CIN * 4) + swz16;
+  const int q_lane = prow * (CIN * 2) + swz16;
+  auto issue_band_of = [&](int m0_, int v) {
+    const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
+    const int npieces_ = (mlast_ - m0_ + 1 + 2 * W + 2 + 2 + 7) >> 3;
+    if (v & 1) {
+      const int base = (m0_ - W - 3) * (CIN * 2) + (v >> 1) * 128;
+      for (int p = wave; p < npieces_; p += 4) {
+        int off = q_lane + base + p * (8 * CIN * 2);
+        if (p == 0 && prow < 2) off = (int)0x80000000;
+        buffer_load_lds16(q_rsrc, Abuf + p * 1024, off, 0);
+      }
+      asm volatile("" ::: "memory");  // (keeps hipcc from merging the two paths into one with a SELECTED descriptor: halo16.h, issue_w)
+      return;
+    }
+    const int base = (m0_ - W - 3) * (CIN * 4) + (v >> 1) * 128;
+    for (int p = wave; p < npieces_; p += 4) {
+      int off = h_lane + base + p * (8 * CIN * 4);
+      if (p == 0 && prow < 2) off = (int)0x80000000;
+      buffer_load_lds16(h_rsrc, Abuf + p * 1024, off, 0);
+    }
+  };
+
+  constexpr int N_EPI_STORES = OUTF32 ? MT * NT : MT * (Q8OUT ? 6 : 4);  // hi16, lo16 (two 32-channel halves each), hi8, lo8
+  static_assert(N_EPI_STORES < 64, "vmcnt range");
+  bool prev_full = false;
+  for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
+  const int xcd = vb & 7, slot = vb >> 3;
+  const int mt_q = (n_mtiles + 7) >> 3;
+  const int mt = (slot / NTILES_N) < mt_q ? xcd * mt_q + slot / NTILES_N : n_mtiles;
+  const int nt = slot % NTILES_N;
+  if (mt >= n_mtiles) break;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int mstart = m0 - W - 1;
+  // weight DMA: LDS row `row` of the tile takes output channel (row & ~15) | perm16_inv(row & 15)
+  int w_off[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    const int j = row & 15;
+    const int srow = (row & ~15) | ((j & 1) ? (j + 7) >> 1 : (j < 8 ? j >> 1 : (j >> 1) + 8));
+    w_off[i] = (n0 + srow) * KROW + (dchunk ^ ((row >> 1) & 7)) * 16;
+  }
+  const rsrc_t w_rsrc = make_rsrc(wgt, COUT * KROW);
+  auto issue_w = [&](int step, int slot_) {  // step = 9 v + tap: bytes [tap][v][128] of the row
+    const int v = step / 9, tap = step - v * 9;
+    const int kofs_bytes = tap * (VC * 128) + v * 128;
+    static_for<WPW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
+    });
+  };
+
+  // ---- consumer side (halo16.h) ----
+  const int mw0 = m0 + wm * WPX + pn;
+  const int q0 = mw0 - mstart + 2;
+  unsigned epk = 0;
+  {
+    const int rem = mw0 % (H * W);
+    int y = rem / W, x = rem - y * W;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+      x += 16 % W, y += 16 / W;
+      if (x >= W) x -= W, y += 1;
+      if (y >= H) y -= H;
+    }
+  }
+  const int rdw0 = (wn * WTN + pn) * 128 + ((g ^ ((pn >> 1) & 7)) << 4);        // f16 weight fragment, k32 step 0, channel tile 0
+  const int rdw8 = (wn * WTN + pn) * 128 + (((2 * g) ^ ((pn >> 1) & 7)) << 4);  // fp8: 16-byte chunks 2 g (and, ^ 16, 2 g + 1)
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)ring;
+  // the f16 step: halo16.h's k_step
+  auto k_step = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
+    constexpr int AH = 3;
+    constexpr int NS = 2 * MT;
+    constexpr bool W1_FIRST = MT - AH < NT;  // (4 sub-tiles: the second k32 step's weights cannot trail behind the activations)
+    frag wf[2][NT];
+    frag af[AH + 1];
+    const unsigned w0 = lds0 + (unsigned)(wst - ring) + (unsigned)rdw0;
+    const unsigned w1 = w0 ^ 64u;
+    unsigned aa[NS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) aa[i] = lds0 + (unsigned)a_addr[i], aa[MT + i] = aa[i] ^ 64u;
+    static_for<NT>([&](auto J) { lds_read16<decltype(J)::value * 2048>(wf[0][decltype(J)::value], w0); });
+    if constexpr (W1_FIRST) static_for<NT>([&](auto J) { lds_read16<decltype(J)::value * 2048>(wf[1][decltype(J)::value], w1); });
+    static_for<AH>([&](auto S) { lds_read16<0>(af[decltype(S)::value], aa[decltype(S)::value]); });
+    __builtin_amdgcn_s_setprio(1);
+    static_for<NS>([&](auto S) {
+      constexpr int s = decltype(S)::value, kk = s / MT, i = s % MT;
+      if constexpr (s + AH < NS) lds_read16<0>(af[(s + AH) % (AH + 1)], aa[s + AH]);
+      if constexpr (!W1_FIRST && s >= 1 && s <= NT) lds_read16<(s - 1) * 2048>(wf[1][s - 1], w1);
+      constexpr int a_after = (s + AH < NS ? AH : NS - 1 - s);
+      constexpr int w_lo = (s - AH > 1 ? s - AH : 1), w_hi = (s < NT ? s : NT);
+      constexpr int w_after = !W1_FIRST && w_hi >= w_lo ? w_hi - w_lo + 1 : 0;
+      wait_lgkmcnt<a_after + w_after>();
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Asm16<T>::mfma(acc[i][j], wf[kk][j], af[s % (AH + 1)]);
+      if constexpr (s == MT / 2) mid();
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the fp8 step: one K = 128 MFMA per accumulator; a fragment = 32 bytes = two ds_read_b128 (chunks 2 g, 2 g + 1 of the row) into
+  // the two halves of an 8-register operand.  Reads in issue order: W[0..NT) (2 each), A[0..AH), then A[s + AH] in sub-step s;
+  // LDS returns in order, so sub-step s waits until only the 2 min(AH, MT - 1 - s) reads issued after A[s] are outstanding
+  auto k_step8 = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
+    constexpr int AH = 2;
+    u32x4 wl[NT], wh[NT], al[AH + 1], ah[AH + 1];
+    const unsigned w0 = lds0 + (unsigned)(wst - ring) + (unsigned)rdw8;
+    const unsigned w1 = w0 ^ 16u;
+    unsigned aa[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) aa[i] = lds0 + (unsigned)a_addr[i];
+    static_for<NT>([&](auto J) {
+      lds_read16<decltype(J)::value * 2048>(wl[decltype(J)::value], w0);
+      lds_read16<decltype(J)::value * 2048>(wh[decltype(J)::value], w1);
+    });
+    static_for<AH>([&](auto S) {
+      lds_read16<0>(al[decltype(S)::value], aa[decltype(S)::value]);
+      lds_read16<0>(ah[decltype(S)::value], aa[decltype(S)::value] ^ 16u);
+    });
+    __builtin_amdgcn_s_setprio(1);
+    static_for<MT>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      if constexpr (s + AH < MT) {
+        lds_read16<0>(al[(s + AH) % (AH + 1)], aa[s + AH]);
+        lds_read16<0>(ah[(s + AH) % (AH + 1)], aa[s + AH] ^ 16u);
+      }
+      wait_lgkmcnt<2 * (s + AH < MT ? AH : MT - 1 - s)>();
+      const i32x8 a = __builtin_bit_cast(i32x8, __builtin_shufflevector(al[s % (AH + 1)], ah[s % (AH + 1)], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const i32x8 w = __builtin_bit_cast(i32x8, __builtin_shufflevector(wl[j], wh[j], 0, 1, 2, 3, 4, 5, 6, 7));
+        mfma_f8_scaled(acc[s][j], w, a, sc_a, sc_b);
+      }
+      if constexpr (s == MT / 2) mid();
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  int s = 0;  // K step counter
+  if (first_tile) {
+    issue_band_of(m0, 0);
+    issue_w(0, 0);  // (later tiles: the previous tile's epilogue has requested both)
+  }
+  for (int c = 0; c < CC; ++c) {
+    static_for<2>([&](auto KIND) {
+      constexpr int kind = decltype(KIND)::value;  // 0: hi band x f16 weights, 1: q8 band x fp8 weights
+      if (c > 0 || kind > 0) {
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
+        issue_band_of(m0, 2 * c + kind);
+      }
+#pragma unroll HIPAC_HALO_TAP_UNROLL
+      for (int tap = 0; tap < 9; ++tap, ++s) {
+        // W(s) must have landed; the band too at tap 0 (it was issued after W(s))
+        if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = (kh - 1) * W + kw - 1;
+        const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+        const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (kh == 2 ? 8u : 0u)) * 0x11111111u;
+        const int qt = q0 + toff;
+        const int x0 = (kind ? g << 5 : g << 4) ^ (((qt >> 1) & 7) << 4);
+        const int a_in = (qt << 7) + x0;
+        const int a_zero = ((qt & 1) << 7) + x0;
+        unsigned em;
+        asm("v_and_b32 %0, %1, %2" : "=v"(em) : "s"(tapmask), "v"(epk));
+        int a_addr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
+        auto mid = [&] {
+          if (s + 1 < NSTEP) issue_w(s + 1, (s + 1) % NSW);  // its slot was freed by this step's barrier
+        };
+        if constexpr (kind) k_step8(wst, a_addr, mid);
+        else k_step(wst, a_addr, mid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    });
+  }
+
+  if constexpr (RESID) {
+    // ---- the residual pair, added on the matrix pipe (halo16.h): D += I x R for the hi plane, then for the lo plane -- both exact
+    const rsrc_t r_rsrc = make_rsrc(resid, M * COUT * 4);
+    const int r_lane = prow * (COUT * 4) + swz16;
+    frag ident[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ident[o][e] = (g == 2 * o + (n16 >> 3) && e == (n16 & 7)) ? (T)1.0f : (T)0.0f;
+    const int r0 = wm * WPX + pn;  // slot of sub-tile 0's pixel
+    const unsigned rb = lds0 + (unsigned)((wn ? Wbuf : Abuf) - ring) + (unsigned)(r0 * 128 + ((g ^ ((r0 >> 1) & 7)) << 4));
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      __builtin_amdgcn_s_barrier();  // every wave has finished the last K step (the other plane's reads): band and ring are free
+      const int r_base = m0 * (COUT * 4) + (n0 + part * COUT) * 2;
+#pragma unroll
+      for (int cch = 0; cch < WN; ++cch)
+#pragma unroll
+        for (int k = 0; k < BM / 8 / 4; ++k) {
+          const int p = wave + 4 * k;
+          buffer_load_lds16(r_rsrc, (cch ? Wbuf : Abuf) + p * 1024, r_lane + r_base + cch * 128 + p * (8 * COUT * 4), 0);
+        }
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      frag rf[4];
+      static_for<2>([&](auto S) { lds_read16<(decltype(S)::value >> 1) * 2048>(rf[decltype(S)::value], (decltype(S)::value & 1) ? rb ^ 64u : rb); });
+      static_for<2 * MT>([&](auto S) {
+        constexpr int s2 = decltype(S)::value, i = s2 >> 1, kk = s2 & 1;
+        if constexpr (s2 + 2 < 2 * MT) lds_read16<((s2 + 2) >> 1) * 2048>(rf[(s2 + 2) & 3], ((s2 + 2) & 1) ? rb ^ 64u : rb);
+        wait_lgkmcnt<(s2 + 2 < 2 * MT) ? 2 : (2 * MT - 1 - s2)>();
+        Asm16<T>::mfma(acc[i][2 * kk], ident[0], rf[s2 & 3]);
+        Asm16<T>::mfma(acc[i][2 * kk + 1], ident[1], rf[s2 & 3]);
+      });
+    }
+  }
+  // ---- epilogue (direct, halo16.h) ----------------------------------------------------------------
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // XDL write -> VALU read of the accumulators
+  float4 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + n0 + wn * WTN + 16 * j + 4 * g);
+  const int c_lane = n0 + wn * WTN + 16 * (g & 1) + 8 * (g >> 1);  // + 32 jp: first of the 8 channels of a 16-bit store
+  __builtin_amdgcn_s_barrier();  // every wave has left the K loop: band and ring are free
+  {
+    // the next tile's first band and first weight tile land behind this epilogue
+    const int vn = vb + gridDim.x;
+    const int mtn = ((vn >> 3) / NTILES_N) < mt_q ? (vn & 7) * mt_q + (vn >> 3) / NTILES_N : n_mtiles;
+    if (mtn < n_mtiles) {
+      issue_band_of(mtn * BM, 0);
+      const int dn = (((vn >> 3) % NTILES_N) * BN - n0) * KROW;
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) w_off[i] += dn;
+      issue_w(0, 0);
+    }
+  }
+  [[maybe_unused]] f32x4 poolS[NT][2];
+  [[maybe_unused]] int pool_slot = 0, pool_bound = 0;
+  [[maybe_unused]] auto pool_flush = [&](int slot_) {
+    float* dst = reinterpret_cast<float*>(outp) + (((size_t)(mt * WM + wm) * kPoolSlots + slot_) * 2) * COUT + n0 + wn * WTN + 4 * g;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = row16_sum(poolS[j][part][e]);
+        if (n16 == 0) *reinterpret_cast<float4*>(dst + part * COUT + 16 * j) = make_float4(t[0], t[1], t[2], t[3]);
+      }
+  };
+  if constexpr (POOL) {
+    constexpr int IMG = H * W;
+    const int mwave = m0 + wm * WPX;
+    pool_slot = mwave / IMG - m0 / IMG;
+    pool_bound = (mwave / IMG + 1) * IMG;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) poolS[j][0] = poolS[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  static_for<MT>([&](auto SUB) {
+    constexpr int i = decltype(SUB)::value;
+    const int m = mw0 + 16 * i;
+    if constexpr (POOL) {
+      // exact two-grid sums: halo16.h's pooled epilogue
+      f32x4 hi[NT], lo[NT];
+      const bool live = m < M;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = live ? fmaxf(v[e], 0.f) : 0.f;
+          hi[j][e] = (v[e] + 12288.0f) - 12288.0f;
+          lo[j][e] = ((v[e] - hi[j][e]) + 0.0234375f) - 0.0234375f;
+        }
+      }
+      if (m0 + wm * WPX + 16 * i + 15 < pool_bound) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) poolS[j][0] += hi[j], poolS[j][1] += lo[j];
+      } else {
+        const bool in_a = m < pool_bound;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) poolS[j][0][e] += in_a ? hi[j][e] : 0.f, poolS[j][1][e] += in_a ? lo[j][e] : 0.f;
+        pool_flush(pool_slot);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) poolS[j][0][e] = in_a ? 0.f : hi[j][e], poolS[j][1][e] = in_a ? 0.f : lo[j][e];
+        ++pool_slot, pool_bound += H * W;
+      }
+      if constexpr (i == MT - 1) {
+        if (pool_slot < kPoolSlots) pool_flush(pool_slot);
+      }
+    } else if constexpr (OUTF32) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+        if constexpr (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (m < M)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * COUT + n0 + wn * WTN + 16 * j + 4 * g) =
+              make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      // lane (n, g): channels 16 j + 4 g .. + 3 of pixel perm16(n).  16-bit planes: v_permlane16_swap on the dwords of tiles
+      // (2 jp, 2 jp + 1) -> 16 contiguous bytes per lane (halo16.h).  Byte planes: one dword (4 channels) per tile; the same swap
+      // gives 8 contiguous bytes per pair (jp = 0: channels 16 (g & 1) + 8 (g >> 1) .. + 7, jp = 1: 32 more), and v_permlane32_swap
+      // of the jp = 0 dwords' upper half with the jp = 1 dwords' lower half joins the two rows g, g ^ 2 that hold neighbouring
+      // 8-channel groups: rows 0, 1 end up with channels 16 g .. + 15, rows 2, 3 with channels 32 + 16 (g & 1) .. + 15.
+      unsigned PH[NT][2], PL[NT][2], QH[NT], QL[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+        float hf[4], lf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (RELU) v[e] = fmaxf(v[e], 0.f);
+          const _Float16 h = (_Float16)v[e];
+          hf[e] = (float)h;
+          lf[e] = (float)(_Float16)(v[e] - hf[e]);
+        }
+        PH[j][0] = PackPair<T>::pack(hf[0], hf[1]), PH[j][1] = PackPair<T>::pack(hf[2], hf[3]);
+        PL[j][0] = PackPair<T>::pack(lf[0], lf[1]), PL[j][1] = PackPair<T>::pack(lf[2], lf[3]);
+        if constexpr (Q8OUT) {
+          QH[j] = cvt4_e4m3(hf[0], hf[1], hf[2], hf[3]);
+          QL[j] = cvt4_e4m3(lf[0] * kQ8LoScale, lf[1] * kQ8LoScale, lf[2] * kQ8LoScale, lf[3] * kQ8LoScale);
+        }
+      }
+      T* const out_h = reinterpret_cast<T*>(outp) + (size_t)m * (2 * COUT) + c_lane;
+#pragma unroll
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        permlane16_swap(PH[2 * jp][0], PH[2 * jp + 1][0]);
+        permlane16_swap(PH[2 * jp][1], PH[2 * jp + 1][1]);
+        permlane16_swap(PL[2 * jp][0], PL[2 * jp + 1][0]);
+        permlane16_swap(PL[2 * jp][1], PL[2 * jp + 1][1]);
+        if (m < M) {
+          *reinterpret_cast<u32x4*>(out_h + 32 * jp) = u32x4{PH[2 * jp][0], PH[2 * jp][1], PH[2 * jp + 1][0], PH[2 * jp + 1][1]};
+          *reinterpret_cast<u32x4*>(out_h + COUT + 32 * jp) = u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]};
+        }
+      }
+      if constexpr (Q8OUT) {
+        permlane16_swap(QH[0], QH[1]), permlane16_swap(QH[2], QH[3]);
+        permlane16_swap(QL[0], QL[1]), permlane16_swap(QL[2], QL[3]);
+        permlane32_swap(QH[0], QH[2]), permlane32_swap(QH[1], QH[3]);
+        permlane32_swap(QL[0], QL[2]), permlane32_swap(QL[1], QL[3]);
+        // the wave's 64 channels are one chunk of the q8 tensor: row [lo8: 64 | hi8: 64]
+        unsigned char* const qrow = out_q + (size_t)m * (2 * COUT) + ((n0 + wn * WTN) >> 6) * 128 + 32 * (g >> 1) + 16 * (g & 1);
+        if (m < M) {
+          *reinterpret_cast<u32x4*>(qrow) = u32x4{QL[0], QL[1], QL[2], QL[3]};
+          *reinterpret_cast<u32x4*>(qrow + 64) = u32x4{QH[0], QH[1], QH[2], QH[3]};
+        }
+      }
+    }
+  });
+  prev_full = !POOL && (m0 + BM <= M);
+  }  // persistent tile loop
+}
+
+}  // namespace hipac

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "e4m3.h"
 
 namespace hipac {
 
@@ -38,8 +39,9 @@ static inline uint16_t f32_to_f16_bits(float f) {
 static inline uint16_t to_bits(float f, int precision) {
   return precision == HIPAC_PREC_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
 }
-static inline int elem_size(int precision) { return precision == HIPAC_PREC_FP32 || precision == HIPAC_PREC_FP16X3 ? 4 : 2; }
-static inline bool wide_mode(int precision) { return precision == HIPAC_PREC_FP32 || precision == HIPAC_PREC_FP16X3; }
+static inline bool pair_mode(int precision) { return precision == HIPAC_PREC_FP16X3 || precision == HIPAC_PREC_FP16Q8; }  // (hi, lo) fp16 pairs
+static inline int elem_size(int precision) { return precision == HIPAC_PREC_FP32 || pair_mode(precision) ? 4 : 2; }
+static inline bool wide_mode(int precision) { return precision == HIPAC_PREC_FP32 || pair_mode(precision); }
 
 static int env_int(const char* name, int dflt, int lo, int hi) {
   if (const char* e = getenv(name)) {
@@ -62,7 +64,7 @@ Plan make_plan(int batch, int precision) {
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
   p.l1_fused = wide_mode(precision) ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
-  p.pool_head = (wide_mode(precision) || !halo_pool_compiled()) ? 0 : env_int("HIPAC_POOL_HEAD", 1, 0, 1);
+  p.pool_head = ((wide_mode(precision) && precision != HIPAC_PREC_FP16Q8) || !halo_pool_compiled()) ? 0 : env_int("HIPAC_POOL_HEAD", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -92,6 +94,11 @@ Plan make_plan(int batch, int precision) {
   p.blk[6] = take(g * 7 * 7 * 512 * e);
   p.blk[7] = take(g * 7 * 7 * 512 * 4);
   p.part = take(((g * 49 + 255) / 256) * 2 * 7 * 2 * 512 * 4);
+  p.q8 = 0;
+  if (precision == HIPAC_PREC_FP16Q8) {
+    const size_t pairs_end = p.blk[7];  // every pair tensor lies below the fp32 map
+    p.q8 = take(pairs_end / 2 + 256);
+  }
   p.total = off;
   return p;
 }
@@ -287,7 +294,7 @@ int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, 
                       hipStream_t s) {
   const long long total = (long long)n * C * H * W;
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (!is_f32 && precision == HIPAC_PREC_FP16X3)
+  if (!is_f32 && pair_mode(precision))
     hipLaunchKernelGGL(tap_export_split_kernel, dim3(grid), dim3(256), 0, s, (const _Float16*)src, dst, n, C, H, W);
   else if (is_f32 || precision == HIPAC_PREC_FP32)
     hipLaunchKernelGGL((tap_export_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, dst, n, C, H, W);
@@ -367,6 +374,40 @@ static int pack_conv_split(const hipac_convbn_t& c, int cout, int cin, int ks, f
   return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
 }
 
+static int pack_conv_split3(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) { return pack_conv_split(c, cout, cin, 3, eps, out); }
+
+// fp16q8, 3x3 / stride 1 convs (halo16x2.h): BN folded, every weight split into the fp16 pair (hi, lo); per output channel and tap,
+// per 64-channel chunk 256 bytes: [hi: 64 fp16 | e4m3(hi * 2^4): 64 | e4m3(lo * 2^15): 64]
+static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) {
+  HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
+                "pack: null tensor pointer (cout=%d cin=%d q8)", cout, cin);
+  HIPAC_REQUIRE(cin % 64 == 0, HIPAC_EINVAL, "pack: q8 layout needs cin %% 64 == 0 (%d)", cin);
+  const size_t KROW = (size_t)9 * (cin / 64) * 256;
+  std::vector<uint8_t> w((size_t)cout * KROW, 0);
+  std::vector<float> bias(cout);
+  for (int o = 0; o < cout; ++o) {
+    const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
+    bias[o] = (float)((double)c.bn_beta[o] - (double)c.bn_mean[o] * scale);
+    for (int i = 0; i < cin; ++i)
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = (float)((double)c.conv_w[((size_t)o * cin + i) * 9 + tap] * scale);
+        const uint16_t hb = f32_to_f16_bits(v);
+        _Float16 hh;
+        memcpy(&hh, &hb, 2);
+        const uint16_t lb = f32_to_f16_bits(v - (float)hh);
+        _Float16 ll;
+        memcpy(&ll, &lb, 2);
+        uint8_t* row = &w[(size_t)o * KROW + ((size_t)tap * (cin / 64) + i / 64) * 256];
+        memcpy(row + (i % 64) * 2, &hb, 2);
+        row[128 + (i % 64)] = f32_to_e4m3(ldexpf((float)hh, 4));
+        row[192 + (i % 64)] = f32_to_e4m3(ldexpf((float)ll, 15));
+      }
+  }
+  int rc = upload(w.data(), w.size(), &out->w);
+  if (rc) return rc;
+  return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
+}
+
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
 // pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the centred byte
 // value v - 128 (exact in bf16 and fp16; bytes outside the image arrive as 0, i.e. -128), so w'' = w * scale / (255 std_c)
@@ -391,7 +432,7 @@ static float round_to(float v, int precision) {
 // precision HIPAC_PREC_FP16X3: w = the hi halves [64][192] followed by the lo halves [64][192] (fp16 pairs)
 static int pack_stem_u8(const hipac_convbn_t& c, float eps, int precision, ConvW* out) {
   const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
-  const bool split = precision == HIPAC_PREC_FP16X3;
+  const bool split = pair_mode(precision);
   std::vector<uint16_t> w((size_t)64 * 192 * (split ? 2 : 1), 0);
   std::vector<float> tab((size_t)16 * 64 + 1);  // + tab[1024]: the factor that undoes the split weights' power-of-two scale
   // fp16x3: the folded weights are ~1e-3 (w / (255 std)), whose lo halves would be fp16 subnormals (2^-24 quantum = only
@@ -527,7 +568,7 @@ void hipac_weights_free(hipac_weights_t* w) {
 int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hipac_weights_t** out) {
   HIPAC_REQUIRE(params && out, HIPAC_EINVAL, "pack: null argument");
   HIPAC_REQUIRE(precision == HIPAC_PREC_BF16 || precision == HIPAC_PREC_FP16 || precision == HIPAC_PREC_FP32 ||
-                    precision == HIPAC_PREC_FP16X3,
+                    precision == HIPAC_PREC_FP16X3 || precision == HIPAC_PREC_FP16Q8,
                 HIPAC_EINVAL, "pack: unknown precision %d", precision);
   HIPAC_REQUIRE(params->num_classes >= 0 && params->num_classes <= 16, HIPAC_EINVAL,
                 "pack: num_classes %d out of range", params->num_classes);
@@ -539,17 +580,20 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   w->net.precision = precision;
   w->net.num_classes = params->num_classes;
   const float eps = params->bn_eps;
-  const bool split = precision == HIPAC_PREC_FP16X3;
-  // fp16x3: the stem runs on the exact f32 MFMA (fp32 weights); every other conv on split pairs
+  const bool split = pair_mode(precision);
+  const bool q8 = precision == HIPAC_PREC_FP16Q8;
+  // fp16x3 / fp16q8: the stem runs on the exact f32 MFMA (fp32 weights); every other conv on split pairs
+  // (fp16q8: the 3x3 / stride 1 convs in halo16x2.h's mixed rows; the entry convs and projections as in fp16x3)
   int rc = pack_conv(params->stem, 64, 3, 7, eps, split ? HIPAC_PREC_FP32 : precision, true, &w->net.stem);
   if (!rc && precision != HIPAC_PREC_FP32) rc = pack_stem_u8(params->stem, eps, precision, &w->net.stem_u8);
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc && split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
-    rc = pack_conv_split(params->block[2 * s][0], ch[s], cin, 3, eps, &w->net.block[2 * s][0]);
-    if (!rc) rc = pack_conv_split(params->block[2 * s][1], ch[s], ch[s], 3, eps, &w->net.block[2 * s][1]);
-    if (!rc) rc = pack_conv_split(params->block[2 * s + 1][0], ch[s], ch[s], 3, eps, &w->net.block[2 * s + 1][0]);
-    if (!rc) rc = pack_conv_split(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, &w->net.block[2 * s + 1][1]);
+    auto pack3 = q8 ? pack_conv_q8 : pack_conv_split3;
+    rc = (s == 0 ? pack3 : pack_conv_split3)(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
+    if (!rc) rc = pack3(params->block[2 * s][1], ch[s], ch[s], eps, &w->net.block[2 * s][1]);
+    if (!rc) rc = pack3(params->block[2 * s + 1][0], ch[s], ch[s], eps, &w->net.block[2 * s + 1][0]);
+    if (!rc) rc = pack3(params->block[2 * s + 1][1], ch[s], ch[s], eps, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0) rc = pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
   }
   for (int s = 0; s < 4 && !rc && !split; ++s) {
@@ -638,7 +682,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   Plan p = L.p;
   HIPAC_REQUIRE(workspace_bytes >= L.total, HIPAC_EWORKSPACE, "forward: workspace %zu < required %zu",
                 workspace_bytes, L.total);
-  const bool split = w->net.precision == HIPAC_PREC_FP16X3;
+  const bool split = pair_mode(w->net.precision);
   HIPAC_REQUIRE(in_layout != HIPAC_IN_U8_HWC || p.fuse_stem || split, HIPAC_EUNSUPPORTED,
                 "forward: uint8 input needs the fused stem (bf16 / fp16 weights, HIPAC_FUSE_STEM not 0) or fp16x3");
   p.u8_input = in_layout == HIPAC_IN_U8_HWC && (!split || p.stem_strip);  // fp16x3 without the strip kernel: converted to fp32 below
@@ -646,6 +690,7 @@ int hipac_resnet18_forward(const hipac_weights_t* w, const void* x, int batch, i
   const size_t in_img_bytes = (size_t)kPadH * kPadW * 4 * p.esz;
   auto trunk = net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
                : net.precision == HIPAC_PREC_FP16 ? run_trunk_f16
+               : net.precision == HIPAC_PREC_FP16Q8 ? run_trunk_f16q8
                : split ? run_trunk_f16x3 : run_trunk_f32;
   // images [i0, i0 + n) on stream s with the lane's own workspace
   auto run_lane = [&](char* ws, int i0, int n, hipStream_t s) -> int {
@@ -738,9 +783,10 @@ int hipac_resnet18_run_ops(const hipac_weights_t* w, const void* x, int in_layou
   HIPAC_REQUIRE(first_op > 0 || x != nullptr || in_layout == HIPAC_IN_NCHW_F32, HIPAC_EINVAL,
                 "run_ops: op 0 needs the input batch");
   char* ws = (char*)workspace;
-  const bool split = w->net.precision == HIPAC_PREC_FP16X3;
+  const bool split = pair_mode(w->net.precision);
   auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
                : w->net.precision == HIPAC_PREC_FP16 ? run_trunk_f16
+               : w->net.precision == HIPAC_PREC_FP16Q8 ? run_trunk_f16q8
                : split ? run_trunk_f16x3 : run_trunk_f32;
   // early ops act on the first sub-batch, late ops on the whole group; an NCHW input was
   // converted into the workspace by the preceding forward
@@ -765,7 +811,7 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
     HIPAC_REQUIRE(!p.fuse_stem, HIPAC_EUNSUPPORTED,
                   "tap 0 (stem) does not exist when the stem is fused with the max-pool; set HIPAC_FUSE_STEM=0");
     src = ws + p.stem, C = 64, H = 112;
-    is_f32 = w->net.precision == HIPAC_PREC_FP16X3;  // its stem map is fp32
+    is_f32 = pair_mode(w->net.precision);  // its stem map is fp32
   } else if (tap == 1) {
     src = ws + p.pool, C = 64, H = 56;
   } else {
@@ -778,7 +824,7 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
       // (same accumulators) on the activations still in the workspace
       Plan q = p;
       q.pool_head = 0;
-      auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : run_trunk_f16;
+      auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : w->net.precision == HIPAC_PREC_FP16Q8 ? run_trunk_f16q8 : run_trunk_f16;
       int rc_t = trunk(w->net, q, (char*)workspace, nullptr, 0, 0, batch, (hipStream_t)stream, kNumOps - 1, kNumOps - 1);
       HIPAC_REQUIRE(rc_t == 0, rc_t, "tap: re-running the last conv failed (%d)", rc_t);
     }
