@@ -392,23 +392,33 @@ def run_resnet(args, rank, world, dev):
             rec["alt_precision"] = {"dtype": alt_name, "value": B * args.steps / (time.perf_counter() - t0),
                                     "unit": "patches/s"}
             nets[alt_name] = alt
-        # the parity mode: fp16 (hi, lo) pairs, three MFMA products per term -- the same workload, the same number of steps
-        netx3 = capi.PackedResNet18(sd, precision="fp16x3")
-        for i in range(max(1, min(2, args.warmup))):
-            netx3.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            netx3.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
-        torch.cuda.synchronize()
-        vx3 = B * args.steps / (time.perf_counter() - t0)
-        rec["parity_mode"] = {"dtype": "fp16x3", "value": vx3, "unit": "patches/s", "patches": B * args.steps,
-                              "tflops_network_arithmetic": vx3 * FLOP_PER_PATCH / 1e12,
-                              "tflops_mfma_issued": 3 * vx3 * FLOP_PER_PATCH / 1e12,
-                              "frac_of_f16_mfma_peak": 3 * vx3 * FLOP_PER_PATCH / 1e12 / PEAK_BF16_DENSE_TFLOPS,
-                              "note": "every product = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2 products in the stem: "
-                                      "bytes are exact); meets_1e-3 is measured in `parity`"}
-        nets["fp16x3"] = netx3
+        # the parity modes (fp16 (hi, lo) pairs; per-patch results within 1e-3 of the reference's fp32 path) -- the same workload, the
+        # same number of steps.  `parity_mode` is the faster one: hi*hi on the fp16 MFMA, the two cross products of every 3x3 / stride 1
+        # conv on the e4m3 MX MFMA (fp16q8); `parity_mode_tight` spends three fp16 products per term (fp16x3)
+        def timed_mode(prec):
+            netp = capi.PackedResNet18(sd, precision=prec)
+            for i in range(max(1, min(2, args.warmup))):
+                netp.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                netp.forward(data[i % pool], want_feats=True, want_logits=True, want_labels=True)
+            torch.cuda.synchronize()
+            nets[prec] = netp
+            return B * args.steps / (time.perf_counter() - t0)
+        vq8 = timed_mode("fp16q8")
+        rec["parity_mode"] = {"dtype": "fp16q8", "value": vq8, "unit": "patches/s", "patches": B * args.steps,
+                              "tflops_network_arithmetic": vq8 * FLOP_PER_PATCH / 1e12,
+                              "note": "every product of the 13 3x3 / stride 1 convs = hi*hi on v_mfma_f32_16x16x32_f16 + (hi*lo + lo*hi) on "
+                                      "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, constant scales): 2 MFMA time units per term; stem and the "
+                                      "stride-2 entry convs as in fp16x3; meets_1e-3 is measured in `parity`"}
+        vx3 = timed_mode("fp16x3")
+        rec["parity_mode_tight"] = {"dtype": "fp16x3", "value": vx3, "unit": "patches/s", "patches": B * args.steps,
+                                    "tflops_network_arithmetic": vx3 * FLOP_PER_PATCH / 1e12,
+                                    "tflops_mfma_issued": 3 * vx3 * FLOP_PER_PATCH / 1e12,
+                                    "frac_of_f16_mfma_peak": 3 * vx3 * FLOP_PER_PATCH / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                                    "note": "every product = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2 products in the stem: "
+                                            "bytes are exact); meets_1e-3 is measured in `parity`"}
         # the debugging reference: fp32 storage, exact f32 MFMA
         net32 = capi.PackedResNet18(sd, precision="fp32")
         n32 = min(B, 2048)
@@ -420,7 +430,8 @@ def run_resnet(args, rank, world, dev):
         v32 = n32 / (time.perf_counter() - t0)
         rec["debug_reference_mode"] = {"dtype": "fp32", "value": v32, "unit": "patches/s", "patches": n32,
                                        "tflops": v32 * FLOP_PER_PATCH / 1e12, "frac_of_f32_mfma_peak": v32 * FLOP_PER_PATCH / 1e12 / PEAK_F32_MFMA_TFLOPS}
-        rec["parity_mode"]["vs_fp32_mode"] = vx3 / v32
+        rec["parity_mode"]["vs_fp32_mode"] = vq8 / v32
+        rec["parity_mode_tight"]["vs_fp32_mode"] = vx3 / v32
         nets["fp32"] = net32
         rec["pcie_inclusive"] = pcie_inclusive(net, data[0], steps=min(4, args.steps))
         if not args.no_cpu_baseline:
@@ -434,13 +445,13 @@ def run_resnet(args, rank, world, dev):
         if world > 1:
             sides = sides[:1]  # configs[3]: one 50k slide per rank, gathered
         w = wsi_object(net, args, rank, world, dev, sides)
-        if rank == 0 and world == 1 and "fp16x3" in nets and sides:
-            # the same scan in the parity mode (fp16x3: per-patch results within 1e-3 of the reference's fp32 path), first side only
+        if rank == 0 and world == 1 and "fp16q8" in nets and sides:
+            # the same scan in the parity mode (fp16q8: per-patch results within 1e-3 of the reference's fp32 path), first side only
             from ss25_hierarchical_multiscale_image_classification_amd import extract
             try:
                 slide = extract.DeviceSlide.synthetic(sides[0], sides[0], seed=10, with_polygons=True)
-                s_per, n_all, n_kept = scan_slide_timed(nets["fp16x3"], slide, args, 1, steps=1, warmup=1, dev=dev)
-                w["parity_mode"] = {"dtype": "u8+fp16x3", "side": sides[0], "s_per_slide": s_per, "kept": n_kept,
+                s_per, n_all, n_kept = scan_slide_timed(nets["fp16q8"], slide, args, 1, steps=1, warmup=1, dev=dev)
+                w["parity_mode"] = {"dtype": "u8+fp16q8", "side": sides[0], "s_per_slide": s_per, "kept": n_kept,
                                     "kept_patches_per_s": n_kept / s_per}
                 del slide
             except (RuntimeError, capi.HipacError) as e:

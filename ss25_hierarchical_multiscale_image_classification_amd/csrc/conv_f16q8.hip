@@ -6,4 +6,5 @@ int run_trunk_f16q8(const Net& net, const Plan& p, char* ws, const void* xin, in
                     hipStream_t s, int first, int last) {
   return run_trunk<_Float16, true, true>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
 }
+bool q8_entry_convs() { return HIPAC_Q8_S2 != 0; }
 }  // namespace hipac

@@ -2944,11 +2944,14 @@ struct Q8Map {
   size_t q8;
   void* of(const void* pairs) const { return ws + q8 + (size_t)((const char*)pairs - ws) / 2; }
 };
-template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false>
+#ifndef HIPAC_Q8_S2
+#define HIPAC_Q8_S2 1  // fp16q8: the stride-2 entry convs on halo16x2.h's stride-2 form (0: the fp16x3 kernels + pairs_to_q8_kernel)
+#endif
+template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false>  // HW: the OUTPUT map
 static int launch_halo16x2(const void* in, const void* in_q, const ConvW& w, const void* resid, void* out, void* out_q, int n, hipStream_t s) {
   constexpr int BM = 256, BN = COUT % 128 == 0 ? 128 : 64;
   constexpr int LDS = halo_band_pieces(HW, BM) * 1024 + 2 * BN * 128;
-  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32>;
+  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32, S2>;
   static bool attr_done[kMaxDevices] = {};
   if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
   const int M = n * HW * HW;
@@ -2990,7 +2993,13 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
     if constexpr (STRIDE == 1) {
       if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
     } else {
-      if constexpr (HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
+      if constexpr (HIPAC_Q8_S2) {
+        // the entry conv on the stride-2 form (reads the q8 tensor the previous stage's last conv wrote); the 1x1 / stride 2
+        // projection shortcut is the fp16x3 kernel
+        if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, true>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
+        if (ops.take())
+          HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false, false, true>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
+      } else if constexpr (HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
         if (ops.take()) {
           HIPAC_TRY((launch_down<T, CI, CO, HI, true>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
           HIPAC_TRY(launch_pairs_to_q8(tmp, qm.of(tmp), (long long)n * HO * HO, CO, s));
@@ -3013,7 +3022,8 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
         if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
         else HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false, true>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
       } else {
-        HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
+        // (HIPAC_Q8_S2: the next stage's entry conv reads this output's q8 tensor)
+        HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, HIPAC_Q8_S2 != 0, false>(tmp, qm.of(tmp), bw1[1], o0, o1, HIPAC_Q8_S2 ? qm.of(o1) : nullptr, n, s)));
       }
     }
     return 0;

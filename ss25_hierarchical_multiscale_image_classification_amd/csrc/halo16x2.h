@@ -78,7 +78,9 @@ static int launch_pairs_to_q8(const void* in, void* q, long long n_pix, int C, h
 // Q8OUT: also write the q8 tensor of the output (for a following conv of this kind).  POOL: the network's last conv -- the pooled
 // fp32 epilogue of halo16.h (partial sums in `outp`), no pair / q8 output.  OUTF32: the fp32 map float[pixel][COUT] instead of pairs.
 // BN: 128 (waves 2 x 2, each 128 px x 64 ch) or 64 (layer1: waves 4 x 1, each 64 px x 64 ch).
-template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false>
+// S2: the 3x3 / STRIDE 2 entry conv of a stage (H x W = the OUTPUT map, the input is 2H x 2W): halo16.h's stride-2 form -- per chunk
+// and operand kind four parity-plane bands (4 / 2 / 2 / 1 taps), gathered pixel by pixel.
+template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16* __restrict__ in, const unsigned char* __restrict__ in_q,
                                                                   const unsigned char* __restrict__ wgt, const float* __restrict__ bias,
                                                                   const _Float16* __restrict__ resid, void* __restrict__ outp,
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   static_assert(BM + 2 * W + 4 <= A_PIECES * 8, "band slots");
   static_assert(!POOL || (BN == 128 && RELU && !Q8OUT && !OUTF32 && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16), "pooled epilogue");
   static_assert(!OUTF32 || !Q8OUT, "the fp32 map has no q8 tensor");
+  static_assert(!S2 || (!RESID && !POOL && !OUTF32), "stride-2 form: plain entry conv");
   static_assert(!RESID || (A_BYTES >= BM * 128 && (WN == 1 || S_BYTES >= BM * 128)), "residual tile: one 64-channel chunk per region");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -123,12 +126,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 
   // bands (halo16.h: slot q = pixel m0 - W - 3 + q, slots 0, 1 zeros, 16-byte chunk c of slot q at c ^ ((q >> 1) & 7)); the hi band
   // comes from the pair tensor (4 CIN bytes per pixel), the q8 band from the byte tensor (2 CIN bytes per pixel)
-  const rsrc_t h_rsrc = make_rsrc(in, M * CIN * 4);
-  const rsrc_t q_rsrc = make_rsrc(in_q, M * CIN * 2);
+  const rsrc_t h_rsrc = make_rsrc(in, (S2 ? 4 : 1) * M * CIN * 4);
+  const rsrc_t q_rsrc = make_rsrc(in_q, (S2 ? 4 : 1) * M * CIN * 2);
   const int swz16 = (dchunk ^ ((4 * wave + (prow >> 1)) & 7)) * 16;
   const int h_lane = prow * (CIN * 4) + swz16;
   const int q_lane = prow * (CIN * 2) + swz16;
+  // S2: per-lane input pixel (2 r, 2 c) of every band piece this wave issues (slot q = 8 p + prow holds output-grid pixel
+  // m0 - W - 3 + q), -1 where the slot is a zero slot or lies outside the batch; made once per tile
+  constexpr int NPB = S2 ? (A_PIECES + 3) / 4 : 1;
+  int b_pix[NPB];
+  auto plane_offsets = [&](int m0_) {
+    if constexpr (S2) {
+#pragma unroll
+      for (int k = 0; k < NPB; ++k) {
+        const int q = 8 * (wave + 4 * k) + prow;
+        const int u = m0_ - W - 3 + q;
+        const int b = u / (H * W), rem = u - b * (H * W), r = rem / W, c = rem - r * W;
+        b_pix[k] = (q >= 2 && u >= 0 && u < M) ? (b * (2 * H) + 2 * r) * (2 * W) + 2 * c : -1;
+      }
+    }
+  };
+  // band of the plane of tap position k (positions 0-3 plane (1,1), 4-5 (0,1), 6-7 (1,0), 8 (0,0)), band v = 2 chunk + kind
+  auto issue_plane_band = [&](int k, int v) {
+    if constexpr (S2) {
+      const int py = k < 4 ? 1 : (k < 6 ? 0 : (k < 8 ? 1 : 0)), px = k < 6 ? 1 : 0;
+      if (v & 1) {
+        const int pofs = (py * 2 * W + px) * (CIN * 2) + (v >> 1) * 128 + swz16;
+#pragma unroll
+        for (int kk = 0; kk < NPB; ++kk) {
+          const int p = wave + 4 * kk;
+          if (p < A_PIECES) buffer_load_lds16(q_rsrc, Abuf + p * 1024, b_pix[kk] < 0 ? (int)0x80000000 : b_pix[kk] * (CIN * 2) + pofs, 0);
+        }
+        asm volatile("" ::: "memory");
+        return;
+      }
+      const int pofs = (py * 2 * W + px) * (CIN * 4) + (v >> 1) * 128 + swz16;
+#pragma unroll
+      for (int kk = 0; kk < NPB; ++kk) {
+        const int p = wave + 4 * kk;
+        if (p < A_PIECES) buffer_load_lds16(h_rsrc, Abuf + p * 1024, b_pix[kk] < 0 ? (int)0x80000000 : b_pix[kk] * (CIN * 4) + pofs, 0);
+      }
+    }
+  };
   auto issue_band_of = [&](int m0_, int v) {
+    if constexpr (S2) {
+      issue_plane_band(0, v);
+      return;
+    }
     const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
     const int npieces_ = (mlast_ - m0_ + 1 + 2 * W + 2 + 2 + 7) >> 3;
     if (v & 1) {
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   const rsrc_t w_rsrc = make_rsrc(wgt, COUT * KROW);
   auto issue_w = [&](int step, int slot_) {  // step = 9 v + tap: bytes [tap][v][128] of the row
     const int v = step / 9, tap = step - v * 9;
-    const int kofs_bytes = tap * (VC * 128) + v * 128;
+    const int kofs_bytes = (S2 ? b16_tap<2>(tap) : tap) * (VC * 128) + v * 128;  // (S2: `tap` is the position in plane order)
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
@@ -188,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     int y = rem / W, x = rem - y * W;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      epk |= (unsigned)((x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == H - 1 ? 8 : 0)) << (4 * i);
+      epk |= (unsigned)((x == 0 ? 1 : 0) | (!S2 && x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (!S2 && y == H - 1 ? 8 : 0)) << (4 * i);
       x += 16 % W, y += 16 / W;
       if (x >= W) x -= W, y += 1;
       if (y >= H) y -= H;
@@ -206,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)ring;
   // the f16 step: halo16.h's k_step
   auto k_step = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
-    constexpr int AH = 3;
+    constexpr int AH = S2 ? 2 : 3;
     constexpr int NS = 2 * MT;
     constexpr bool W1_FIRST = MT - AH < NT;  // (4 sub-tiles: the second k32 step's weights cannot trail behind the activations)
     frag wf[2][NT];
@@ -238,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   // the two halves of an 8-register operand.  Reads in issue order: W[0..NT) (2 each), A[0..AH), then A[s + AH] in sub-step s;
   // LDS returns in order, so sub-step s waits until only the 2 min(AH, MT - 1 - s) reads issued after A[s] are outstanding
   auto k_step8 = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
-    constexpr int AH = 2;
+    constexpr int AH = S2 ? 1 : 2;  // (S2: the per-lane plane offsets need the registers; a sub-step is 128 cycles of MFMA)
     u32x4 wl[NT], wh[NT], al[AH + 1], ah[AH + 1];
     const unsigned w0 = lds0 + (unsigned)(wst - ring) + (unsigned)rdw8;
     const unsigned w1 = w0 ^ 16u;
@@ -273,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   };
 
   int s = 0;  // K step counter
+  if constexpr (S2) {
+    if (first_tile) plane_offsets(m0);  // (later tiles: made by the previous tile's epilogue, for its band prefetch)
+  }
   if (first_tile) {
     issue_band_of(m0, 0);
     issue_w(0, 0);  // (later tiles: the previous tile's epilogue has requested both)
@@ -286,14 +333,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       }
 #pragma unroll HIPAC_HALO_TAP_UNROLL
       for (int tap = 0; tap < 9; ++tap, ++s) {
+        if (S2 && (tap == 4 || tap == 6 || tap == 8)) {  // the next plane's band (its round trip is exposed: the wait below drains it)
+          __builtin_amdgcn_s_barrier();
+          issue_plane_band(tap, 2 * c + kind);
+        }
         // W(s) must have landed; the band too at tap 0 (it was issued after W(s))
         if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int toff = (kh - 1) * W + kw - 1;
+        const int tap_w = S2 ? b16_tap<2>(tap) : tap;  // the tap's index in the weights
+        const int kh = tap_w / 3, kw = tap_w - kh * 3;
+        const int toff = S2 ? (kh == 0 ? -W : 0) + (kw == 0 ? -1 : 0) : (kh - 1) * W + kw - 1;
         const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
-        const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (kh == 2 ? 8u : 0u)) * 0x11111111u;
+        const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (!S2 && kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (!S2 && kh == 2 ? 8u : 0u)) * 0x11111111u;
         const int qt = q0 + toff;
         const int x0 = (kind ? g << 5 : g << 4) ^ (((qt >> 1) & 7) << 4);
         const int a_in = (qt << 7) + x0;
@@ -360,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     const int vn = vb + gridDim.x;
     const int mtn = ((vn >> 3) / NTILES_N) < mt_q ? (vn & 7) * mt_q + (vn >> 3) / NTILES_N : n_mtiles;
     if (mtn < n_mtiles) {
+      if constexpr (S2) plane_offsets(mtn * BM);
       issue_band_of(mtn * BM, 0);
       const int dn = (((vn >> 3) % NTILES_N) * BN - n0) * KROW;
 #pragma unroll

@@ -590,7 +590,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   for (int s = 0; s < 4 && !rc && split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
     auto pack3 = q8 ? pack_conv_q8 : pack_conv_split3;
-    rc = (s == 0 ? pack3 : pack_conv_split3)(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
+    rc = (s == 0 || q8_entry_convs() ? pack3 : pack_conv_split3)(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
     if (!rc) rc = pack3(params->block[2 * s][1], ch[s], ch[s], eps, &w->net.block[2 * s][1]);
     if (!rc) rc = pack3(params->block[2 * s + 1][0], ch[s], ch[s], eps, &w->net.block[2 * s + 1][0]);
     if (!rc) rc = pack3(params->block[2 * s + 1][1], ch[s], ch[s], eps, &w->net.block[2 * s + 1][1]);

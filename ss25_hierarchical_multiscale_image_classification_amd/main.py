@@ -12,7 +12,7 @@ the reference (patch_features_L.npy, patch_labels_L.npy, patch_paths_L.txt).
 
 Additive flags: ``--data_root``, ``--synthetic W,H,SEED[,NAME]`` (repeatable; a slide
 made on the GPU instead of a file), ``--write_png`` (also emit the reference's PNG
-tree), ``--precision {bf16,fp16,fp16x3,fp32}``, ``--weights PATH``, ``--stride N``,
+tree), ``--precision {bf16,fp16,fp16x3,fp16q8,fp32}``, ``--weights PATH``, ``--stride N``,
 ``--world_size N`` (one process per GPU over RCCL where the reference wraps its model in
 nn.DataParallel, src/main.py:481-482, :841-842: ``--patch`` / ``--extract_features`` shard the
 slides, ``--train*`` the batches; started by this program itself before it touches a GPU).
@@ -54,9 +54,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--data_root", type=str, default=None)
     p.add_argument("--synthetic", action="append", default=[], metavar="W,H,SEED[,NAME]")
     p.add_argument("--write_png", action="store_true")
-    p.add_argument("--precision", choices=["bf16", "fp16", "fp16x3", "fp32"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "fp16", "fp16x3", "fp16q8", "fp32"], default="bf16",
                    help="MFMA operand type; fp16x3 = parity mode (fp16 pairs, three products per term: the reference's fp32 "
-                        "results to 1e-3 at ~1/3 of the bf16 throughput); fp32 = debugging reference (exact f32 MFMA, ~1/9)")
+                        "results to 1e-3 at ~1/3 of the bf16 throughput); fp16q8 = the faster parity mode (the same pairs, cross "
+                        "products on the e4m3 MX MFMA: logits within ~1e-5); fp32 = debugging reference (exact f32 MFMA, ~1/9)")
     p.add_argument("--weights", type=str, default=None, help="state_dict (.pth, any reference key layout)")
     p.add_argument("--stride", type=int, default=None, help="window stride (default: the reference's 224)")
     p.add_argument("--epochs", type=int, default=None)

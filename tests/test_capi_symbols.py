@@ -33,8 +33,9 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     # the header's number, the library's and the binding's are one number (bumped whenever entry points or enums are added)
     header = open(os.path.join(ROOT, "include", "hipac.h")).read()
     hdr = int(re.search(r"#define HIPAC_ABI_VERSION (\d+)", header).group(1))
-    assert lib.hipac_abi_version() == hdr == capi.ABI_VERSION == 7
+    assert lib.hipac_abi_version() == hdr == capi.ABI_VERSION == 8
     assert int(re.search(r"#define HIPAC_PREC_FP16X3 (\d+)", header).group(1)) == capi.PRECISIONS["fp16x3"]
+    assert int(re.search(r"#define HIPAC_PREC_FP16Q8 (\d+)", header).group(1)) == capi.PRECISIONS["fp16q8"]
 
 
 def test_resample_coeffs_match_pillow_restatement(lib):

@@ -54,7 +54,7 @@ def _oracle_rows(levels_np, polys, sd, levels):
     return np.array(rows, np.int32), ref_f, ref_l
 
 
-@pytest.mark.parametrize("prec,tol", [("fp16x3", 2e-5), ("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 2e-5), ("fp16q8", 1e-4), ("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2.5e-2)])
 def test_score_slide_all_levels_matches_oracle(prec, tol):
     """(fp16x3 = the parity mode: north_star's 1e-3 on features AND logits, asserted here at 2e-5 (measured 1.5e-6 /
     3.7e-6), labels identical.)
@@ -80,7 +80,7 @@ def test_score_slide_all_levels_matches_oracle(prec, tol):
         torch.cuda.synchronize()
         assert np.array_equal(meta.cpu().numpy(), rows)  # same windows, same labels, reference order
         assert rel(feats, ref_f) <= tol and rel(logits, ref_l) <= tol, (prec, kw)
-        if prec == "fp16x3":
+        if prec in ("fp16x3", "fp16q8"):
             assert rel(feats, ref_f) <= 1e-3 and rel(logits, ref_l) <= 1e-3
         margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
         decided = margin > 2 * tol * ref_l.abs().max()

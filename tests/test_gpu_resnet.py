@@ -6,6 +6,9 @@ MI355X in brackets -- the arithmetic is fp32-accumulated MFMA on operands rounde
 named type, so the error is rounding only:
     fp16x3 : features 2e-5 [1.6e-6]  logits 2e-5 [2.7e-6]  taps 2e-5   THE PARITY MODE: (hi, lo) fp16 pairs, three
            MFMA products per term; north_star's 1e-3 is asserted below with a factor 50 to spare
+    fp16q8 : features 1e-4 [7.5e-6]  logits 1e-4 [8.5e-6]  taps 1e-4 [<= 2.9e-5]   the FASTER parity mode: the same pairs, hi x hi on
+           the fp16 MFMA, the two cross products of the 3x3 / stride 1 convs on the e4m3 MX MFMA with constant scales (halo16x2.h);
+           north_star's 1e-3 asserted with a factor 10 to spare
     fp32 : features 2e-5   logits 2e-5   taps 2e-5   (debugging reference: fp32 storage, exact f32 MFMA; the
            only differences from the oracle are BN folding and summation order)
     fp16 : features 1e-3 [4-6e-4]   logits 2e-3 [0.8-1.3e-3]   intermediate taps 3e-3 [<=1.3e-3]
@@ -30,8 +33,8 @@ from ss25_hierarchical_multiscale_image_classification_amd import capi, synth
 pytestmark = pytest.mark.gpu
 TOL = {"fp16": dict(feat=1e-3, out=2e-3, tap=3e-3), "bf16": dict(feat=2.5e-2, out=2.5e-2, tap=3e-2),
        "fp32": dict(feat=2e-5, out=2e-5, tap=2e-5),  # "out" bounds the logits, "feat" the 512-d features
-       "fp16x3": dict(feat=2e-5, out=2e-5, tap=2e-5)}
-WIDE = ("fp32", "fp16x3")  # modes whose stem map exists (float input) and whose bounds sit far inside 1e-3
+       "fp16x3": dict(feat=2e-5, out=2e-5, tap=2e-5), "fp16q8": dict(feat=1e-4, out=1e-4, tap=1e-4)}
+WIDE = ("fp32", "fp16x3", "fp16q8")  # modes whose stem map exists (float input) and whose bounds sit far inside 1e-3
 TAPS = ["stem", "maxpool"] + [f"layer{s}.{k}" for s in (1, 2, 3, 4) for k in (0, 1)]
 
 
@@ -52,7 +55,7 @@ def golden_sd(golden, seed):
     return sd
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8", "fp32", "fp16", "bf16"])
 @pytest.mark.parametrize("seed", [0, 1])
 def test_golden_features_logits_labels(golden, prec, seed):
     u8 = torch.from_numpy(golden["patches_u8"]).cuda()
@@ -77,7 +80,7 @@ def test_golden_features_logits_labels(golden, prec, seed):
         assert float((t.cpu() - ref).abs().max()) <= TOL[prec]["tap"] * scale, name
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8", "fp32", "fp16", "bf16"])
 def test_full_taps_against_oracle_random_patches(prec):
     sd = synth.seeded_resnet18_state_dict(2, num_classes=2)
     u8 = synth.synth_patches_u8(5, seed=11)
@@ -180,7 +183,7 @@ def test_layer1_fused_block_equals_separate_convs(monkeypatch, n):
         assert rel(f1, f0) <= 40 * ulp and rel(l1, l0) <= 80 * ulp, (prec, rel(f1, f0), rel(l1, l0))
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8", "fp16", "bf16"])
 def test_uint8_strip_kernel_against_oracle(prec):
     """The default uint8 path (strip kernel: normalisation folded into the stem weights, pooling in
     registers): its pooled stem map, features and logits against the oracle, on patches with extreme
@@ -352,24 +355,24 @@ def test_fp16x3_uint8_strip_stem_equals_float_stem_path(monkeypatch):
     assert rel(pool1, pool2) <= 1e-5 and rel(f1, f2) <= 1e-5 and rel(l1, l2) <= 1e-5
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp32"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8", "fp32"])
 def test_parity_mode_meets_1e3_with_margin_and_labels_exactly(prec):
     """The strict form of north_star's gate: logits / features within 1e-3 of the fp32 oracle
-    (here: < 2e-5) and per-patch labels identical, on 24 seeded patches incl. uint8 input."""
+    (here: < 2e-5; fp16q8 < 1e-4) and per-patch labels identical, on 24 seeded patches incl. uint8 input."""
     sd = synth.seeded_resnet18_state_dict(7, num_classes=2)
     u8 = synth.synth_patches_u8(24, seed=31)
     x = torch.stack([torch.from_numpy(T.to_tensor_normalize(p.numpy())) for p in u8])
     ref_f, ref_l = R.resnet18_forward(x, sd)
     net = capi.PackedResNet18(sd, precision=prec)
     f, l, lab = net.forward(u8.cuda(), want_logits=True, want_labels=True)  # uint8 in (fp32: normalised by the LUT kernel)
-    assert rel(f, ref_f) < 2e-5 and rel(l, ref_l) < 2e-5
+    assert rel(f, ref_f) < TOL[prec]["feat"] and rel(l, ref_l) < TOL[prec]["out"]
     elem = float(((f.cpu() - ref_f).abs() / ref_f.abs().clamp_min(1e-3)).max())
     assert elem < 1e-3  # element-wise relative, not just norm-relative
     margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
-    assert torch.equal(lab.cpu()[margin > 1e-5], ref_l.argmax(1)[margin > 1e-5])
+    assert torch.equal(lab.cpu()[margin > 5 * TOL[prec]["out"] * float(ref_l.abs().max())], ref_l.argmax(1)[margin > 5 * TOL[prec]["out"] * float(ref_l.abs().max())])
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8", "fp32", "fp16", "bf16"])
 def test_configs0_256_patches_against_oracle(prec):
     """BASELINE configs[0] / SURVEY 8(d): 256 seeded random 224x224x3 patches, seeded state_dict #0, uint8 input
     (the benchmarked entry form).  fp16x3 (the parity mode) and fp32: features and logits within 1e-3 (asserted at 2e-5;
@@ -385,7 +388,7 @@ def test_configs0_256_patches_against_oracle(prec):
     ef, el = rel(f, ref_f), rel(l, ref_l)
     print(f"configs[0] {prec}: features {ef:.2e} logits {el:.2e}")
     if prec in WIDE:
-        assert ef <= 1e-3 and el <= 1e-3 and ef <= 2e-5 and el <= 2e-5
+        assert ef <= 1e-3 and el <= 1e-3 and ef <= TOL[prec]["feat"] and el <= TOL[prec]["out"]
     else:
         assert ef <= TOL[prec]["feat"] and el <= TOL[prec]["out"]
     margin = (ref_l[:, 0] - ref_l[:, 1]).abs()
@@ -410,13 +413,14 @@ def test_large_ragged_batches_two_lanes_default_schedule(n):
     assert torch.equal(lab, torch.cat([p[2] for p in pieces]))
 
 
-def test_fp16x3_ragged_batch_sub_batches_and_lanes(monkeypatch):
-    # fp16x3 through the sub-batch / group / two-lane schedule: 150 patches in sub-batches of 16 and groups of 32 on two
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16q8"])
+def test_fp16x3_ragged_batch_sub_batches_and_lanes(monkeypatch, prec):
+    # the pair modes through the sub-batch / group / two-lane schedule: 150 patches in sub-batches of 16 and groups of 32 on two
     # lanes == the same patches scored in pieces on one lane, bit for bit
     monkeypatch.setenv("HIPAC_SUBBATCH", "16")
     monkeypatch.setenv("HIPAC_GROUP", "32")
     sd = synth.seeded_resnet18_state_dict(3, num_classes=2)
-    net = capi.PackedResNet18(sd, precision="fp16x3")
+    net = capi.PackedResNet18(sd, precision=prec)
     u8 = synth.synth_patches_u8(150, seed=8, device="cuda")
     f, l, lab = net.forward(u8, want_logits=True, want_labels=True)
     monkeypatch.setenv("HIPAC_LANES", "1")
