@@ -80,11 +80,17 @@ static int launch_pairs_to_q8(const void* in, void* q, long long n_pix, int C, h
 // BN: 128 (waves 2 x 2, each 128 px x 64 ch) or 64 (layer1: waves 4 x 1, each 64 px x 64 ch).
 // S2: the 3x3 / STRIDE 2 entry conv of a stage (H x W = the OUTPUT map, the input is 2H x 2W): halo16.h's stride-2 form -- per chunk
 // and operand kind four parity-plane bands (4 / 2 / 2 / 1 taps), gathered pixel by pixel.
-template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false>
+// PCIN > 0: the BasicBlock's 1x1 / stride 2 projection shortcut folded in (halo16.h, PCIN): 2 PCIN / 64 more K steps -- per
+// 64-channel chunk of the block input `resid` (pairs [n][2H][2W][PCIN], q8 tensor `resid_q`) its pixel (2y, 2x) gathered at the
+// centre tap's slots, first the hi plane x the projection's f16 weights, then the q8 row x its e4m3 weights (`wgt_p`:
+// [COUT][PCIN / 64][hi16: 64 | whi8: 64 | wlo8: 64]); `bias` = the conv's + the projection's.
+template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16* __restrict__ in, const unsigned char* __restrict__ in_q,
                                                                   const unsigned char* __restrict__ wgt, const float* __restrict__ bias,
                                                                   const _Float16* __restrict__ resid, void* __restrict__ outp,
-                                                                  unsigned char* __restrict__ out_q, int M, int n_img, int n_mtiles) {
+                                                                  unsigned char* __restrict__ out_q, int M, int n_img, int n_mtiles,
+                                                                  const unsigned char* __restrict__ resid_q = nullptr,
+                                                                  const unsigned char* __restrict__ wgt_p = nullptr) {
   using T = _Float16;
   using frag = f16x8;
   constexpr int BM = 256, NSW = 2;
@@ -99,14 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   constexpr int W_BYTES = BN * 128;
   constexpr int WPW = BN / 8 / 4;
   constexpr int NTILES_N = COUT / BN;
-  constexpr int NSTEP = 9 * VC;
+  constexpr int PCC = PCIN / 64;                    // chunks of the folded projection (0: none)
+  constexpr int NSTEP = 9 * VC + 2 * PCC;
   constexpr int S_BYTES = NSW * W_BYTES;
   static_assert((BN == 64 || BN == 128) && CIN % 64 == 0 && COUT % BN == 0 && (MT == 8 || MT == 4) && NT == 4, "tile shape");
   static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
   static_assert(BM + 2 * W + 4 <= A_PIECES * 8, "band slots");
   static_assert(!POOL || (BN == 128 && RELU && !Q8OUT && !OUTF32 && (BM + H * W - 1) / (H * W) + 1 <= kPoolSlots && H * W > 16), "pooled epilogue");
   static_assert(!OUTF32 || !Q8OUT, "the fp32 map has no q8 tensor");
-  static_assert(!S2 || (!RESID && !POOL && !OUTF32), "stride-2 form: plain entry conv");
+  static_assert(!S2 || (!RESID && !POOL && !OUTF32 && PCIN == 0), "stride-2 form: plain entry conv");
+  static_assert(PCIN % 64 == 0 && (PCIN == 0 || !RESID), "folded projection replaces the residual input");
   static_assert(!RESID || (A_BYTES >= BM * 128 && (WN == 1 || S_BYTES >= BM * 128)), "residual tile: one 64-channel chunk per region");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -206,15 +214,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   const int mstart = m0 - W - 1;
   // weight DMA: LDS row `row` of the tile takes output channel (row & ~15) | perm16_inv(row & 15)
   int w_off[WPW];
+  int wp_off[PCC > 0 ? WPW : 1];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int row = (wave + 4 * i) * 8 + prow;
     const int j = row & 15;
     const int srow = (row & ~15) | ((j & 1) ? (j + 7) >> 1 : (j < 8 ? j >> 1 : (j >> 1) + 8));
     w_off[i] = (n0 + srow) * KROW + (dchunk ^ ((row >> 1) & 7)) * 16;
+    if constexpr (PCC > 0) wp_off[i] = (n0 + srow) * (PCC * 256) + (dchunk ^ ((row >> 1) & 7)) * 16;
   }
   const rsrc_t w_rsrc = make_rsrc(wgt, COUT * KROW);
+  const rsrc_t wp_rsrc = make_rsrc(PCC > 0 ? wgt_p : wgt, COUT * (PCC > 0 ? PCC * 256 : KROW));
   auto issue_w = [&](int step, int slot_) {  // step = 9 v + tap: bytes [tap][v][128] of the row
+    if (PCC > 0 && step >= 9 * VC) {  // uniform: a projection step, row bytes [pc][kind][128]
+      const int kofs_p = (step - 9 * VC) * 128;
+      static_for<WPW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        buffer_load_lds16(wp_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, wp_off[PCC > 0 ? i : 0], kofs_p);
+      });
+      asm volatile("" ::: "memory");  // (see issue_band_of)
+      return;
+    }
     const int v = step / 9, tap = step - v * 9;
     const int kofs_bytes = (S2 ? b16_tap<2>(tap) : tap) * (VC * 128) + v * 128;  // (S2: `tap` is the position in plane order)
     static_for<WPW>([&](auto I) {
@@ -363,6 +383,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     });
+  }
+
+  if constexpr (PCC > 0) {
+    // ---- the folded projection: per chunk pc the gathered hi rows x f16 weights, then the gathered q8 rows x e4m3 weights; centre
+    // tap only, no image-edge cases (pixel (2y, 2x) always exists).  Rows outside the tile's pixels are sent out of range (zeros).
+    const rsrc_t ph_rsrc = make_rsrc(resid, 4 * M * PCIN * 4);
+    const rsrc_t pq_rsrc = make_rsrc(resid_q, 4 * M * PCIN * 2);
+    const int mlast = (m0 + BM <= M ? m0 + BM : M) - 1;
+    const int first = W + 3, last = first + (mlast - m0);  // slots that hold the tile's pixels
+    for (int pc = 0; pc < PCC; ++pc) {
+      static_for<2>([&](auto KIND) {
+        constexpr int kind = decltype(KIND)::value;
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
+        for (int p = wave + (first >> 3); p <= (last >> 3); p += 4) {
+          const int q = p * 8 + prow;
+          const int mm = m0 + q - first;
+          const bool ok = q >= first && q <= last;
+          const int b = mm / (H * W), rem = mm - b * (H * W), y = rem / W, x = rem - y * W;
+          const int pix = (b * (2 * H) + 2 * y) * (2 * W) + 2 * x;
+          const int schunk = (dchunk ^ ((q >> 1) & 7)) * 16;
+          if constexpr (kind) buffer_load_lds16(pq_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 2) + pc * 128 + schunk : (int)0x80000000, 0);
+          else buffer_load_lds16(ph_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 4) + pc * 128 + schunk : (int)0x80000000, 0);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+        const int a_in = (q0 << 7) + ((kind ? g << 5 : g << 4) ^ (((q0 >> 1) & 7) << 4));
+        int a_addr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_addr[i] = a_in + 2048 * i;
+        auto mid = [&] {
+          if (s + 1 < NSTEP) issue_w(s + 1, (s + 1) % NSW);
+        };
+        if constexpr (kind) k_step8(wst, a_addr, mid);
+        else k_step(wst, a_addr, mid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++s;
+      });
+    }
   }
 
   if constexpr (RESID) {

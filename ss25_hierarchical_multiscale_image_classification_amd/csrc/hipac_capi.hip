@@ -378,19 +378,19 @@ static int pack_conv_split3(const hipac_convbn_t& c, int cout, int cin, float ep
 
 // fp16q8, 3x3 / stride 1 convs (halo16x2.h): BN folded, every weight split into the fp16 pair (hi, lo); per output channel and tap,
 // per 64-channel chunk 256 bytes: [hi: 64 fp16 | e4m3(hi * 2^4): 64 | e4m3(lo * 2^15): 64]
-static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) {
+static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out, int taps) {
   HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
                 "pack: null tensor pointer (cout=%d cin=%d q8)", cout, cin);
   HIPAC_REQUIRE(cin % 64 == 0, HIPAC_EINVAL, "pack: q8 layout needs cin %% 64 == 0 (%d)", cin);
-  const size_t KROW = (size_t)9 * (cin / 64) * 256;
+  const size_t KROW = (size_t)taps * (cin / 64) * 256;
   std::vector<uint8_t> w((size_t)cout * KROW, 0);
   std::vector<float> bias(cout);
   for (int o = 0; o < cout; ++o) {
     const double scale = (double)c.bn_gamma[o] / sqrt((double)c.bn_var[o] + (double)eps);
     bias[o] = (float)((double)c.bn_beta[o] - (double)c.bn_mean[o] * scale);
     for (int i = 0; i < cin; ++i)
-      for (int tap = 0; tap < 9; ++tap) {
-        const float v = (float)((double)c.conv_w[((size_t)o * cin + i) * 9 + tap] * scale);
+      for (int tap = 0; tap < taps; ++tap) {
+        const float v = (float)((double)c.conv_w[((size_t)o * cin + i) * taps + tap] * scale);
         const uint16_t hb = f32_to_f16_bits(v);
         _Float16 hh;
         memcpy(&hh, &hb, 2);
@@ -407,6 +407,8 @@ static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, C
   if (rc) return rc;
   return upload(bias.data(), bias.size() * 4, (void**)&out->bias);
 }
+
+static int pack_conv_q8_3x3(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) { return pack_conv_q8(c, cout, cin, eps, out, 9); }
 
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
 // pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the centred byte
@@ -589,12 +591,14 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc && split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
-    auto pack3 = q8 ? pack_conv_q8 : pack_conv_split3;
+    auto pack3 = q8 ? pack_conv_q8_3x3 : pack_conv_split3;
     rc = (s == 0 || q8_entry_convs() ? pack3 : pack_conv_split3)(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
     if (!rc) rc = pack3(params->block[2 * s][1], ch[s], ch[s], eps, &w->net.block[2 * s][1]);
     if (!rc) rc = pack3(params->block[2 * s + 1][0], ch[s], ch[s], eps, &w->net.block[2 * s + 1][0]);
     if (!rc) rc = pack3(params->block[2 * s + 1][1], ch[s], ch[s], eps, &w->net.block[2 * s + 1][1]);
-    if (!rc && s > 0) rc = pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
+    if (!rc && s > 0)
+      rc = q8 && q8_entry_convs() ? pack_conv_q8(params->down[s - 1], ch[s], cin, eps, &w->net.down[s - 1], 1)  // (folded into conv2: halo16x2.h, PCIN)
+                                  : pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
   }
   for (int s = 0; s < 4 && !rc && !split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
@@ -604,7 +608,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     if (!rc) rc = pack_conv(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0) rc = pack_conv(params->down[s - 1], ch[s], cin, 1, eps, precision, false, &w->net.down[s - 1]);
   }
-  for (int st = 1; st < 4 && !rc && !wide_mode(precision); ++st) {
+  for (int st = 1; st < 4 && !rc && (!wide_mode(precision) || q8); ++st) {
     // block0.conv2's bias + the projection's, for the kernel that accumulates both into one accumulator
     const hipac_convbn_t& a = params->block[2 * st][1];
     const hipac_convbn_t& b = params->down[st - 1];
