@@ -1609,14 +1609,16 @@ constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 // [64][192] followed by the lo halves [64][192]; hi stays in registers, lo is fetched from LDS per channel plane, and
 // every fragment feeds two MFMAs per (row, row pair).  The pooling stays in fp32 (v_max3 in y, two DPP shifts in x,
 // ReLU) and the pooled rows leave as (hi, lo) pairs [pixel][hi: 64 | lo: 64], hi then lo through the same staging.
-template <typename T, bool SPLIT = false>
+// Q8 (precision fp16q8): the pooled map's q8 tensor [pixel][lo8: 64 | hi8: 64] (halo16x2.h) is written too, from the same staging.
+template <typename T, bool SPLIT = false, bool Q8 = false>
 __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned char* __restrict__ x,
                                                                   const T* __restrict__ wgt,
                                                                   const float* __restrict__ btab, T* __restrict__ out,
-                                                                  int n_strips, int in_bytes) {
+                                                                  int n_strips, int in_bytes, unsigned char* __restrict__ out_q = nullptr) {
   using E = Elem<T>;
   using frag = typename E::frag;
   static_assert(!SPLIT || std::is_same<T, _Float16>::value, "split pairs are fp16");
+  static_assert(!Q8 || SPLIT, "the q8 tensor belongs to the pair layout");
   constexpr int OPIX = SPLIT ? 128 : 64;              // elements per output pixel
   constexpr int WLO_BYTES = SPLIT ? 2 * 12 * 1024 : 0;  // low weight halves in fragment order: [channel half][k16 step][lane] x 16 B
   constexpr int NRP = 11, PXW = 128;
@@ -1656,6 +1658,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
     const int q = (pix * 147) >> 11, k = pix - 14 * q;
     // SPLIT: the staging holds two pooled rows at a time, hi rows then lo rows: staged row q = (half, row & 1)
     s_off[m] = SPLIT ? ((q & 1) * 56 + k) * 128 + (q >> 1) * 64 + (c & 3) * 8 : (q * 56 + k) * 64 + (c & 3) * 8;
+  }
+  // Q8: staged items c < 112 are the hi halves of (pooled row c / 56, pixel, 8 channels), item c + 112 the lo halves of the same
+  int q_off[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c = lane + 64 * m, pix = c >> 2;
+    const int q = pix >= 14 ? 1 : 0, k = pix - 14 * q;
+    q_off[m] = (q * 56 + k) * 128 + (c & 3) * 8;
   }
 
   const float unscale = SPLIT ? btab[16 * 64] : 1.f;  // 2^-S of the split weights' scale (pack_stem_u8)
@@ -1788,6 +1798,24 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             for (int m = 0; m < 4; ++m)
               if (m < 3 || lane < 32)
                 *reinterpret_cast<u32x4*>(dst0 + g * (2 * 56 * 128) + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
+            if constexpr (Q8) {
+              unsigned char* const qdst0 = out_q + ((((size_t)b * 56 + 4 * ys) * 56 + 28 * side + 14 * st) * 128 + jt * 32) + g * (2 * 56 * 128);
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+                if (m < 1 || lane < 48) {
+                  const f16x8 hv = *reinterpret_cast<const f16x8*>(Sl + (lane + 64 * m) * 16);
+                  const f16x8 lv = *reinterpret_cast<const f16x8*>(Sl + (lane + 64 * m + 112) * 16);
+                  u32x2 h8, l8;
+#pragma unroll
+                  for (int k = 0; k < 2; ++k) {
+                    h8[k] = cvt4_e4m3((float)hv[4 * k], (float)hv[4 * k + 1], (float)hv[4 * k + 2], (float)hv[4 * k + 3]);
+                    l8[k] = cvt4_e4m3((float)lv[4 * k] * kQ8LoScale, (float)lv[4 * k + 1] * kQ8LoScale, (float)lv[4 * k + 2] * kQ8LoScale,
+                                      (float)lv[4 * k + 3] * kQ8LoScale);
+                  }
+                  *reinterpret_cast<u32x2*>(qdst0 + q_off[m]) = l8;
+                  *reinterpret_cast<u32x2*>(qdst0 + q_off[m] + 64) = h8;
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the rows are overwritten
           };
           // one pooled row at a time: y max (fp32, v_max3), round to T, then the x max of lanes r, r+1, r+2 by two
@@ -1879,7 +1907,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
             issue_dma(tg, 0);  // prologue: nothing was requested yet
             wait_vmcnt<0>();
           } else {
-            wait_vmcnt<SPLIT ? 8 : 4>();  // this wave's raw rows of step n+1 (requested at the end of H2(n-1)) are older than its 4 (8) stores
+            wait_vmcnt<Q8 ? 16 : SPLIT ? 8 : 4>();  // this wave's raw rows of step n+1 (requested at the end of H2(n-1)) are older than its 4 (8; Q8: 16) stores
           }
           HALO_STAMP(z_tw);
 #ifdef HIPAC_ABL_STRIP_NO_CONVERT
@@ -3123,11 +3151,10 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
         const int n_strips = 2 * ne;
         const int n_pairs = (n_strips + 1) / 2;
         const int sgrid = n_pairs < 256 ? n_pairs : 256;
-        hipLaunchKernelGGL((stem_pool_strip2_kernel<T, true>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
+        hipLaunchKernelGGL((stem_pool_strip2_kernel<T, true, Q8>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
                            (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
-                           ne * kPatch * kPatch * 3);
+                           ne * kPatch * kPatch * 3, Q8 ? (unsigned char*)qm.of(ws + p.pool) : nullptr);
         HIPAC_TRY((int)hipGetLastError());
-        if constexpr (Q8) HIPAC_TRY(launch_pairs_to_q8(ws + p.pool, qm.of(ws + p.pool), (long long)ne * 56 * 56, 64, s));
       }
       (void)ops.take();
     } else {
