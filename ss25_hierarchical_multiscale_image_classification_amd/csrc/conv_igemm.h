@@ -2975,12 +2975,12 @@ struct Q8Map {
 #ifndef HIPAC_Q8_S2
 #define HIPAC_Q8_S2 1  // fp16q8: the stride-2 entry convs on halo16x2.h's stride-2 form (0: the fp16x3 kernels + pairs_to_q8_kernel)
 #endif
-template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0>  // HW: the OUTPUT map
+template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0, bool LO16 = true>  // HW: the OUTPUT map
 static int launch_halo16x2(const void* in, const void* in_q, const ConvW& w, const void* resid, void* out, void* out_q, int n, hipStream_t s,
                            const void* resid_q = nullptr, const void* wgt_p = nullptr, const float* bias = nullptr) {
   constexpr int BM = 256, BN = COUT % 128 == 0 ? 128 : 64;
-  constexpr int LDS = halo_band_pieces(HW, BM) * 1024 + 2 * BN * 128;
-  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32, S2, PCIN>;
+  constexpr int LDS = halo_band_pieces(HW, BM) * 1024 + (BN == 64 ? HIPAC_Q8_NSW64 : 2) * BN * 128;
+  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32, S2, PCIN, LO16>;
   static bool attr_done[kMaxDevices] = {};
   if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
   const int M = n * HW * HW;
@@ -3020,17 +3020,17 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
     const void* idt = x;
     const void* c2_in = tmp;
     if constexpr (STRIDE == 1) {
-      if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
+      if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, false, 0, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
     } else {
       if constexpr (HIPAC_Q8_S2) {
         // the entry conv on the stride-2 form (reads the q8 tensor the previous stage's last conv wrote); the 1x1 / stride 2
         // projection shortcut rides in the block's second conv as extra K steps (its op slot is empty)
-        if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, true>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
+        if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, true, 0, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
         (void)ops.take();
         if (ops.take())
           HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, CI>(c2_in, qm.of(c2_in), bw[1], x, o0, qm.of(o0), n, s, qm.of(x),
                                                                                               net.down[stage - 1].w, net.bias_c2p[stage - 1])));
-        if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
+        if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, 0, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
         if (ops.take()) {
           if constexpr (LAST) {
             if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
@@ -3057,7 +3057,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
       idt = ds;
     }
     if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, true, false>(c2_in, qm.of(c2_in), bw[1], idt, o0, qm.of(o0), n, s)));
-    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
+    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, 0, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
     if (ops.take()) {
       if constexpr (LAST) {
         if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));

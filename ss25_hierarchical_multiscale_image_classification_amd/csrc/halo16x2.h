@@ -24,6 +24,13 @@
 // chunk c, 9 taps of 32 fp8 MFMAs of twice the cycles: 2 MFMA-time units per term where fp16x3 spends 3.
 #pragma once
 
+#ifndef HIPAC_Q8_ABL
+#define HIPAC_Q8_ABL 0  // developer builds (wrong results): 1 no epilogue arithmetic / stores, 2 no residual pass, 4 no fp8 steps, 8 no f16 steps
+#endif
+#ifndef HIPAC_Q8_NSW64
+#define HIPAC_Q8_NSW64 4  // weight ring slots of the BN = 64 (layer1) form: 2 .. 4
+#endif
+
 namespace hipac {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -84,7 +91,10 @@ static int launch_pairs_to_q8(const void* in, void* q, long long n_pix, int C, h
 // 64-channel chunk of the block input `resid` (pairs [n][2H][2W][PCIN], q8 tensor `resid_q`) its pixel (2y, 2x) gathered at the
 // centre tap's slots, first the hi plane x the projection's f16 weights, then the q8 row x its e4m3 weights (`wgt_p`:
 // [COUT][PCIN / 64][hi16: 64 | whi8: 64 | wlo8: 64]); `bias` = the conv's + the projection's.
-template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0>
+// LO16: write the lo plane of the output pairs.  Only a later residual add reads it (the next conv takes the hi plane and the q8
+// tensor), so a block's FIRST conv leaves it out: a third of its output bytes and stores.
+template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0,
+          bool LO16 = true>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16* __restrict__ in, const unsigned char* __restrict__ in_q,
                                                                   const unsigned char* __restrict__ wgt, const float* __restrict__ bias,
                                                                   const _Float16* __restrict__ resid, void* __restrict__ outp,
@@ -93,7 +103,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
                                                                   const unsigned char* __restrict__ wgt_p = nullptr) {
   using T = _Float16;
   using frag = f16x8;
-  constexpr int BM = 256, NSW = 2;
+  constexpr int BM = 256;
+  // weight ring depth: a BN = 64 step is only 512 cycles of MFMA per wave, less than the weight DMA's round trip, and its 8 KB
+  // tiles leave room for four slots (three steps of distance); BN = 128: two slots, one step (1024 cycles) of distance
+  constexpr int NSW = BN == 64 ? HIPAC_Q8_NSW64 : 2;
   constexpr int CC = CIN / 64;                      // 64-channel chunks
   constexpr int VC = 2 * CC;                        // bands of the K loop: chunk c's hi band (v = 2c), then its q8 band (v = 2c + 1)
   constexpr int KROW = 9 * VC * 128;                // bytes per weight row (output channel)
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     }
   };
 
-  constexpr int N_EPI_STORES = OUTF32 ? MT * NT : MT * (Q8OUT ? 6 : 4);  // hi16, lo16 (two 32-channel halves each), hi8, lo8
+  constexpr int N_EPI_STORES = OUTF32 ? MT * NT : MT * (2 + (LO16 ? 2 : 0) + (Q8OUT ? 2 : 0));  // hi16, lo16 (two 32-channel halves each), hi8, lo8
+  static_assert(LO16 || Q8OUT, "an output without lo plane and without q8 tensor is a plain fp16 map");
   static_assert(N_EPI_STORES < 64, "vmcnt range");
   bool prev_full = false;
   for (int vb = blockIdx.x, first_tile = 1;; vb += gridDim.x, first_tile = 0) {
@@ -342,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   }
   if (first_tile) {
     issue_band_of(m0, 0);
-    issue_w(0, 0);  // (later tiles: the previous tile's epilogue has requested both)
+#pragma unroll
+    for (int ps = 0; ps < NSW - 1; ++ps) issue_w(ps, ps);  // (later tiles: the previous tile's epilogue has requested all of these)
   }
   for (int c = 0; c < CC; ++c) {
     static_for<2>([&](auto KIND) {
@@ -357,8 +372,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
           __builtin_amdgcn_s_barrier();
           issue_plane_band(tap, 2 * c + kind);
         }
-        // W(s) must have landed; the band too at tap 0 (it was issued after W(s))
+        // W(s) must have landed -- W(s + 1 .. s + NSW - 2) were requested after it and may stay in flight; the band too at tap 0 and
+        // behind a plane switch (it was requested after them all: drain)
         if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
+        else if (NSW > 2 && tap != 0 && !(S2 && (tap == 4 || tap == 6 || tap == 8)) && s + NSW - 2 < NSTEP) wait_vmcnt<(NSW - 2) * WPW>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         const int tap_w = S2 ? b16_tap<2>(tap) : tap;  // the tap's index in the weights
@@ -376,10 +393,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
         auto mid = [&] {
-          if (s + 1 < NSTEP) issue_w(s + 1, (s + 1) % NSW);  // its slot was freed by this step's barrier
+          if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);  // its slot (step s - 1's) was freed by this step's barrier
         };
-        if constexpr (kind) k_step8(wst, a_addr, mid);
-        else k_step(wst, a_addr, mid);
+        if constexpr (kind) {
+          if constexpr (HIPAC_Q8_ABL & 4) mid();
+          else k_step8(wst, a_addr, mid);
+        } else {
+          if constexpr (HIPAC_Q8_ABL & 8) mid();
+          else k_step(wst, a_addr, mid);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     });
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_addr[i] = a_in + 2048 * i;
         auto mid = [&] {
-          if (s + 1 < NSTEP) issue_w(s + 1, (s + 1) % NSW);
+          if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
         };
         if constexpr (kind) k_step8(wst, a_addr, mid);
         else k_step(wst, a_addr, mid);
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     }
   }
 
-  if constexpr (RESID) {
+  if constexpr (RESID && !(HIPAC_Q8_ABL & 2)) {
     // ---- the residual pair, added on the matrix pipe (halo16.h): D += I x R for the hi plane, then for the lo plane -- both exact
     const rsrc_t r_rsrc = make_rsrc(resid, M * COUT * 4);
     const int r_lane = prow * (COUT * 4) + swz16;
@@ -434,20 +456,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
       for (int e = 0; e < 8; ++e) ident[o][e] = (g == 2 * o + (n16 >> 3) && e == (n16 & 7)) ? (T)1.0f : (T)0.0f;
     const int r0 = wm * WPX + pn;  // slot of sub-tile 0's pixel
-    const unsigned rb = lds0 + (unsigned)((wn ? Wbuf : Abuf) - ring) + (unsigned)(r0 * 128 + ((g ^ ((r0 >> 1) & 7)) << 4));
+    const unsigned rb0 = lds0 + (unsigned)((wn ? Wbuf : Abuf) - ring) + (unsigned)(r0 * 128 + ((g ^ ((r0 >> 1) & 7)) << 4));
+    // (BN = 64 with a 32 KB ring: both planes in ONE round trip, the hi tile into the band region, the lo tile into the ring)
+    constexpr bool BOTH = WN == 1 && S_BYTES >= BM * 128;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
-      __builtin_amdgcn_s_barrier();  // every wave has finished the last K step (the other plane's reads): band and ring are free
-      const int r_base = m0 * (COUT * 4) + (n0 + part * COUT) * 2;
+      if (!BOTH || part == 0) {
+        __builtin_amdgcn_s_barrier();  // every wave has finished the last K step (the other plane's reads): band and ring are free
 #pragma unroll
-      for (int cch = 0; cch < WN; ++cch)
+        for (int pl = 0; pl < (BOTH ? 2 : 1); ++pl) {
+          const int r_base = m0 * (COUT * 4) + (n0 + (BOTH ? pl : part) * COUT) * 2;
 #pragma unroll
-        for (int k = 0; k < BM / 8 / 4; ++k) {
-          const int p = wave + 4 * k;
-          buffer_load_lds16(r_rsrc, (cch ? Wbuf : Abuf) + p * 1024, r_lane + r_base + cch * 128 + p * (8 * COUT * 4), 0);
+          for (int cch = 0; cch < WN; ++cch)
+#pragma unroll
+            for (int k = 0; k < BM / 8 / 4; ++k) {
+              const int p = wave + 4 * k;
+              buffer_load_lds16(r_rsrc, (cch || pl ? Wbuf : Abuf) + p * 1024, r_lane + r_base + cch * 128 + p * (8 * COUT * 4), 0);
+            }
         }
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      const unsigned rb = BOTH && part ? rb0 + (unsigned)(Wbuf - Abuf) : rb0;
       frag rf[4];
       static_for<2>([&](auto S) { lds_read16<(decltype(S)::value >> 1) * 2048>(rf[decltype(S)::value], (decltype(S)::value & 1) ? rb ^ 64u : rb); });
       static_for<2 * MT>([&](auto S) {
@@ -476,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       const int dn = (((vn >> 3) % NTILES_N) * BN - n0) * KROW;
 #pragma unroll
       for (int i = 0; i < WPW; ++i) w_off[i] += dn;
-      issue_w(0, 0);
+#pragma unroll
+      for (int ps = 0; ps < NSW - 1; ++ps) issue_w(ps, ps);
     }
   }
   [[maybe_unused]] f32x4 poolS[NT][2];
@@ -501,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
     for (int j = 0; j < NT; ++j) poolS[j][0] = poolS[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  static_for<MT>([&](auto SUB) {
+  static_for<(HIPAC_Q8_ABL & 1) ? 0 : MT>([&](auto SUB) {
     constexpr int i = decltype(SUB)::value;
     const int m = mw0 + 16 * i;
     if constexpr (POOL) {
@@ -555,35 +586,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       // gives 8 contiguous bytes per pair (jp = 0: channels 16 (g & 1) + 8 (g >> 1) .. + 7, jp = 1: 32 more), and v_permlane32_swap
       // of the jp = 0 dwords' upper half with the jp = 1 dwords' lower half joins the two rows g, g ^ 2 that hold neighbouring
       // 8-channel groups: rows 0, 1 end up with channels 16 g .. + 15, rows 2, 3 with channels 32 + 16 (g & 1) .. + 15.
+      // Arithmetic per PAIR of values (packed fp32 adds / multiplies, packed conversions): h = rn16(v) as a pair, l = v - h exactly,
+      // lo16 = rn16(l); the byte planes come from the unrounded v and l -- e4m3(min(v, 448)), e4m3(clamp(l * 2^11)) -- one rounding
+      // each instead of two.
       unsigned PH[NT][2], PL[NT][2], QH[NT], QL[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-        float hf[4], lf[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if constexpr (RELU) v[e] = fmaxf(v[e], 0.f);
-          const _Float16 h = (_Float16)v[e];
-          hf[e] = (float)h;
-          lf[e] = (float)(_Float16)(v[e] - hf[e]);
-        }
-        PH[j][0] = PackPair<T>::pack(hf[0], hf[1]), PH[j][1] = PackPair<T>::pack(hf[2], hf[3]);
-        PL[j][0] = PackPair<T>::pack(lf[0], lf[1]), PL[j][1] = PackPair<T>::pack(lf[2], lf[3]);
-        if constexpr (Q8OUT) {
-          QH[j] = cvt4_e4m3(hf[0], hf[1], hf[2], hf[3]);
-          QL[j] = cvt4_e4m3(lf[0] * kQ8LoScale, lf[1] * kQ8LoScale, lf[2] * kQ8LoScale, lf[3] * kQ8LoScale);
-        }
+        const f32x2 bb[2] = {f32x2{bv[j].x, bv[j].y}, f32x2{bv[j].z, bv[j].w}};
+        int q_h = 0, q_l = 0;
+        static_for<2>([&](auto HP) {
+          constexpr int hp = decltype(HP)::value;
+          const f32x2 u = f32x2{acc[i][j][2 * hp], acc[i][j][2 * hp + 1]} + bb[hp];
+          f32x2 v = u;
+          if constexpr (RELU) v = f32x2{fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
+          const f16x2 h2 = __builtin_convertvector(v, f16x2);
+          PH[j][hp] = __builtin_bit_cast(unsigned, h2);
+          const f32x2 l = v - __builtin_convertvector(h2, f32x2);
+          if constexpr (LO16) PL[j][hp] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2));
+          if constexpr (Q8OUT) {
+            const f32x2 ls = l * f32x2{kQ8LoScale, kQ8LoScale};
+            // (v_med3 on the value BEFORE the ReLU: ReLU and the clamp at 448 in one, and no canonicalising v_max in front of a
+            // v_min; the first conversion of a dword takes a dead register as its `old` operand instead of a zero that needs a move)
+            const float c0 = __builtin_amdgcn_fmed3f(u[0], RELU ? 0.f : -448.f, 448.f), c1 = __builtin_amdgcn_fmed3f(u[1], RELU ? 0.f : -448.f, 448.f);
+            const float d0 = __builtin_amdgcn_fmed3f(ls[0], -448.f, 448.f), d1 = __builtin_amdgcn_fmed3f(ls[1], -448.f, 448.f);
+            q_h = __builtin_amdgcn_cvt_pk_fp8_f32(c0, c1, hp == 0 ? __builtin_bit_cast(int, u[0]) : q_h, hp == 1);
+            q_l = __builtin_amdgcn_cvt_pk_fp8_f32(d0, d1, hp == 0 ? __builtin_bit_cast(int, ls[0]) : q_l, hp == 1);
+          }
+        });
+        QH[j] = (unsigned)q_h, QL[j] = (unsigned)q_l;
       }
       T* const out_h = reinterpret_cast<T*>(outp) + (size_t)m * (2 * COUT) + c_lane;
 #pragma unroll
       for (int jp = 0; jp < NT / 2; ++jp) {
         permlane16_swap(PH[2 * jp][0], PH[2 * jp + 1][0]);
         permlane16_swap(PH[2 * jp][1], PH[2 * jp + 1][1]);
-        permlane16_swap(PL[2 * jp][0], PL[2 * jp + 1][0]);
-        permlane16_swap(PL[2 * jp][1], PL[2 * jp + 1][1]);
+        if constexpr (LO16) {
+          permlane16_swap(PL[2 * jp][0], PL[2 * jp + 1][0]);
+          permlane16_swap(PL[2 * jp][1], PL[2 * jp + 1][1]);
+        }
         if (m < M) {
           *reinterpret_cast<u32x4*>(out_h + 32 * jp) = u32x4{PH[2 * jp][0], PH[2 * jp][1], PH[2 * jp + 1][0], PH[2 * jp + 1][1]};
-          *reinterpret_cast<u32x4*>(out_h + COUT + 32 * jp) = u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]};
+          if constexpr (LO16) *reinterpret_cast<u32x4*>(out_h + COUT + 32 * jp) = u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]};
         }
       }
       if constexpr (Q8OUT) {
@@ -600,7 +643,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       }
     }
   });
-  prev_full = !POOL && (m0 + BM <= M);
+  prev_full = !POOL && !(HIPAC_Q8_ABL & 1) && (m0 + BM <= M);
+  if constexpr (HIPAC_Q8_ABL & 1) {  // keep the accumulators alive
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) reinterpret_cast<float*>(outp)[0] = t;
+  }
   }  // persistent tile loop
 }
 
