@@ -27,6 +27,10 @@
 #ifndef HIPAC_Q8_ABL
 #define HIPAC_Q8_ABL 0  // developer builds (wrong results): 1 no epilogue arithmetic / stores, 2 no residual pass, 4 no fp8 steps, 8 no f16 steps
 #endif
+#ifndef HIPAC_Q8_DEPHASE
+#define HIPAC_Q8_DEPHASE 0  // > 0: the workgroups that take a CU's second slot (dispatch order: XCD-local index 32 .. 63) start N x 8128
+                            // cycles late, so that one workgroup's epilogue meets the other's K loop
+#endif
 #ifndef HIPAC_Q8_NSW64
 #define HIPAC_Q8_NSW64 4  // weight ring slots of the BN = 64 (layer1) form: 2 .. 4
 #endif
@@ -214,6 +218,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     }
   };
 
+  if constexpr (HIPAC_Q8_DEPHASE > 0) {
+    if ((blockIdx.x >> 3) & 32) {
+#pragma unroll
+      for (int k = 0; k < HIPAC_Q8_DEPHASE; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   constexpr int N_EPI_STORES = OUTF32 ? MT * NT : MT * (2 + (LO16 ? 2 : 0) + (Q8OUT ? 2 : 0));  // hi16, lo16 (two 32-channel halves each), hi8, lo8
   static_assert(LO16 || Q8OUT, "an output without lo plane and without q8 tensor is a plain fp16 map");
   static_assert(N_EPI_STORES < 64, "vmcnt range");
