@@ -67,6 +67,29 @@ for _s, (_ci, _co, _ho) in enumerate(((64, 64, 56), (64, 128, 28), (128, 256, 14
     OPS.append((f"l{_s+1}b1c2", _conv_macs(_co, _co, 3, _ho)))
 assert len(OPS) == 21 and sum(m for _, m in OPS) + 1024 == 1_813_562_368
 
+def op_bytes(op: str) -> int:
+    """ALGORITHMIC HBM bytes of one trunk op per patch in the 2-byte precisions (every input element read once, every output
+    element written once; weights -- shared by the whole launch -- and halo re-reads not counted): what the op's HBM roofline is
+    priced with in `per_op` (hbm_frac).  The early layers move 0.6-0.8 MB per patch and op: at the measured rates that is
+    2.5-3.8 TB/s, i.e. HBM is as close a bound for them as the MFMA pipe (profiles/r04/pmc_per_kernel.csv has the counters)."""
+    if op.startswith("stem"):
+        return 224 * 224 * 3 + 56 * 56 * 64 * 2
+    st = int(op[1]) - 1
+    ci, co, ho = ((64, 64, 56), (64, 128, 28), (128, 256, 14), (256, 512, 7))[st]
+    out = ho * ho * co * 2
+    if op in ("l1b0", "l1b1"):
+        return 2 * out  # the fused block: its input (also the shortcut) and its output
+    if op.endswith("b0c1"):
+        return (2 * ho) * (2 * ho) * ci * 2 + out
+    if op.endswith("b0c1+proj"):
+        return (2 * ho) * (2 * ho) * ci * 2 + 2 * out
+    if op.endswith("b0c2+proj"):
+        return out + ho * ho * ci * 2 + out  # conv input, the block input's pixels (2y, 2x), output
+    if op.endswith("b0c2") or op.endswith("b1c2"):
+        return (2 * out if op != "l4b1c2" else out) + out  # input, shortcut, output (the last conv leaves pooled sums, not a map)
+    return 2 * out  # b1c1, l4proj
+
+
 KERNEL_OF_OP = {"stem7x7+pool": "stem_pool_strip2_kernel", "l1": "block16_c64_kernel" if L1_FUSED else "conv3x3_c64_kernel", "l4proj": "conv_glds_kernel"}
 
 
@@ -368,9 +391,12 @@ def run_resnet(args, rank, world, dev):
                            "traffic": traffic, "launch_ms": dom["ms"], "flops_per_launch": dom["flops_per_launch"],
                            "images_per_launch": dom["images"]}
         # (the op slots a fused kernel leaves empty are not work: their "time" is the event pair's own overhead -- left out)
+        # frac = of the dense MFMA peak; hbm_gbs / hbm_frac = the op's algorithmic bytes (op_bytes) over its time, of the 8 TB/s peak
         rec["per_op"] = [{"op": o["op"], "kernel": kernel_of(o["op"]), "images": o["images"],
                           "ms": round(o["ms"], 4), "tflops": round(o["tflops"], 1),
-                          "frac": round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3)} for o in ops if o["tflops"]]
+                          "frac": round(o["tflops"] / PEAK_BF16_DENSE_TFLOPS, 3),
+                          "hbm_gbs": round(op_bytes(o["op"]) * o["images"] / (o["ms"] * 1e-3) / 1e9, 0),
+                          "hbm_frac": round(op_bytes(o["op"]) * o["images"] / (o["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)} for o in ops if o["tflops"]]
         if traffic is not None:
             tj = json.load(open(tpath))
             rec["roofline"]["traffic_source"] = ("profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), "

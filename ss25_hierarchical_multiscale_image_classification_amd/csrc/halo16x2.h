@@ -25,11 +25,17 @@
 #pragma once
 
 #ifndef HIPAC_Q8_ABL
-#define HIPAC_Q8_ABL 0  // developer builds (wrong results): 1 no epilogue arithmetic / stores, 2 no residual pass, 4 no fp8 steps, 8 no f16 steps
+#define HIPAC_Q8_ABL 0  // developer builds (wrong results): 1 no epilogue arithmetic / stores, 2 no residual pass, 4 no fp8 steps, 8 no f16 steps, 16 epilogue arithmetic but no pair / byte stores
 #endif
 #ifndef HIPAC_Q8_DEPHASE
 #define HIPAC_Q8_DEPHASE 0  // > 0: the workgroups that take a CU's second slot (dispatch order: XCD-local index 32 .. 63) start N x 8128
                             // cycles late, so that one workgroup's epilogue meets the other's K loop
+#endif
+#ifndef HIPAC_Q8_PRE_ALL
+#define HIPAC_Q8_PRE_ALL 1  // 1: a tile's first NSW weight tiles (every ring slot) are requested BEFORE the previous tile's epilogue stores,
+                            // and steps 1 .. NSW - 1 wait for no vector-memory operation: vmcnt retires in issue order, so a weight tile
+                            // requested after the stores could only be waited for by draining every one of them (each stays counted until
+                            // its data is in L2).  0: NSW - 1 tiles ahead, the first in-loop request at step 0 (halo16.h's schedule)
 #endif
 #ifndef HIPAC_Q8_NSW64
 #define HIPAC_Q8_NSW64 4  // weight ring slots of the BN = 64 (layer1) form: 2 .. 4
@@ -124,6 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   constexpr int NTILES_N = COUT / BN;
   constexpr int PCC = PCIN / 64;                    // chunks of the folded projection (0: none)
   constexpr int NSTEP = 9 * VC + 2 * PCC;
+  constexpr int PRE = HIPAC_Q8_PRE_ALL ? NSW : NSW - 1;  // weight tiles requested ahead of a tile's first step
+  static_assert(NSTEP > NSW, "K steps");
   constexpr int S_BYTES = NSW * W_BYTES;
   static_assert((BN == 64 || BN == 128) && CIN % 64 == 0 && COUT % BN == 0 && (MT == 8 || MT == 4) && NT == 4, "tile shape");
   static_assert(A_BYTES + S_BYTES <= 80 * 1024, "LDS: two workgroups per CU");
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   if (first_tile) {
     issue_band_of(m0, 0);
 #pragma unroll
-    for (int ps = 0; ps < NSW - 1; ++ps) issue_w(ps, ps);  // (later tiles: the previous tile's epilogue has requested all of these)
+    for (int ps = 0; ps < PRE; ++ps) issue_w(ps, ps);  // (later tiles: the previous tile's epilogue has requested all of these)
   }
   for (int c = 0; c < CC; ++c) {
     static_for<2>([&](auto KIND) {
@@ -385,8 +393,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         // W(s) must have landed -- W(s + 1 .. s + NSW - 2) were requested after it and may stay in flight; the band too at tap 0 and
         // behind a plane switch (it was requested after them all: drain)
         if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
-        else if (NSW > 2 && tap != 0 && !(S2 && (tap == 4 || tap == 6 || tap == 8)) && s + NSW - 2 < NSTEP) wait_vmcnt<(NSW - 2) * WPW>();
-        else wait_vmcnt<0>();
+        else if (tap != 0 && !(S2 && (tap == 4 || tap == 6 || tap == 8))) {
+          if (HIPAC_Q8_PRE_ALL && s < NSW) {
+            // W(s) was requested ahead of the tile and step 0's wait covered it
+          } else if (NSW > 2 && s + NSW - 2 < NSTEP) wait_vmcnt<(NSW - 2) * WPW>();
+          else wait_vmcnt<0>();
+        } else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         const int tap_w = S2 ? b16_tap<2>(tap) : tap;  // the tap's index in the weights
         const int kh = tap_w / 3, kw = tap_w - kh * 3;
@@ -403,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
         auto mid = [&] {
-          if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);  // its slot (step s - 1's) was freed by this step's barrier
+          // the slot of step s - 1 was freed by this step's barrier (PRE_ALL: at step 0 there is no such slot, every one was filled ahead)
+          if (s + NSW - 1 < NSTEP && (!HIPAC_Q8_PRE_ALL || s > 0)) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
         };
         if constexpr (kind) {
           if constexpr (HIPAC_Q8_ABL & 4) mid();
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
 #pragma unroll
       for (int i = 0; i < WPW; ++i) w_off[i] += dn;
 #pragma unroll
-      for (int ps = 0; ps < NSW - 1; ++ps) issue_w(ps, ps);
+      for (int ps = 0; ps < PRE; ++ps) issue_w(ps, ps);
     }
   }
   [[maybe_unused]] f32x4 poolS[NT][2];
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
           permlane16_swap(PL[2 * jp][0], PL[2 * jp + 1][0]);
           permlane16_swap(PL[2 * jp][1], PL[2 * jp + 1][1]);
         }
-        if (m < M) {
+        if ((HIPAC_Q8_ABL & 16) ? m < 0 : m < M) {
           *reinterpret_cast<u32x4*>(out_h + 32 * jp) = u32x4{PH[2 * jp][0], PH[2 * jp][1], PH[2 * jp + 1][0], PH[2 * jp + 1][1]};
           if constexpr (LO16) *reinterpret_cast<u32x4*>(out_h + COUT + 32 * jp) = u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]};
         }
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         permlane32_swap(QL[0], QL[2]), permlane32_swap(QL[1], QL[3]);
         // the wave's 64 channels are one chunk of the q8 tensor: row [lo8: 64 | hi8: 64]
         unsigned char* const qrow = out_q + (size_t)m * (2 * COUT) + ((n0 + wn * WTN) >> 6) * 128 + 32 * (g >> 1) + 16 * (g & 1);
-        if (m < M) {
+        if ((HIPAC_Q8_ABL & 16) ? m < 0 : m < M) {
           *reinterpret_cast<u32x4*>(qrow) = u32x4{QL[0], QL[1], QL[2], QL[3]};
           *reinterpret_cast<u32x4*>(qrow + 64) = u32x4{QH[0], QH[1], QH[2], QH[3]};
         }
