@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void block16_c64_kernel(const T* __restrict
       permlane16_swap(P[0][0], P[1][0]);
       permlane16_swap(P[0][1], P[1][1]);
       char* const dst = reinterpret_cast<char*>(out) + ((size_t)(unsigned)(pix0 + (y0 + rho) * W) << 7) + out_lane;
-      if (lx < 14) *reinterpret_cast<u32x4*>(dst) = u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
+      if (lx < 14) store16_out<HIPAC_NT_STORES != 0>(dst, u32x4{P[0][0], P[0][1], P[1][0], P[1][1]});
     }
   };
   int pend_pix = 0, pend_sl = 0;

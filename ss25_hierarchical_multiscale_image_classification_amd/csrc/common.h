@@ -17,6 +17,20 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#ifndef HIPAC_NT_STORES
+#define HIPAC_NT_STORES 0  // 1: the conv epilogues of the big early maps (layer1's fused block, layer2's convs) store their activations
+                           // non-temporally (streamed past the L2's LRU).  Measured (bf16): the ops timed ALONE get faster (layer2 160 / 218 /
+                           // 193 / 227 -> 146 / 205 / 187 / 202 ns per patch; layers 3-4 2-5 % slower, the fp16q8 kernels +-0), but the whole
+                           // forward gets 0.5 % SLOWER (318.9 k vs 320.6 k patches/s, three alternating runs on one box): inside the
+                           // pipeline the next kernel finds part of a 100-200 MB map still in the L2 / infinity cache, which a per-op
+                           // loop that never reads its output cannot show.  Left off.
+#endif
+// 16-byte activation store of a conv epilogue
+template <bool NT>
+__device__ __forceinline__ void store16_out(void* p, u32x4 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 

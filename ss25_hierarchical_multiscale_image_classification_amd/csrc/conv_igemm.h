@@ -1609,6 +1609,9 @@ constexpr int kStripSteps = 14;  // 56 pooled rows / 4 per step
 // [64][192] followed by the lo halves [64][192]; hi stays in registers, lo is fetched from LDS per channel plane, and
 // every fragment feeds two MFMAs per (row, row pair).  The pooling stays in fp32 (v_max3 in y, two DPP shifts in x,
 // ReLU) and the pooled rows leave as (hi, lo) pairs [pixel][hi: 64 | lo: 64], hi then lo through the same staging.
+#ifndef HIPAC_NT_STEM
+#define HIPAC_NT_STEM 0  // 1: the strip stem's pooled-map stores are non-temporal (see HIPAC_NT_STORES)
+#endif
 // Q8 (precision fp16q8): the pooled map's q8 tensor [pixel][lo8: 64 | hi8: 64] (halo16x2.h) is written too, from the same staging.
 template <typename T, bool SPLIT = false, bool Q8 = false>
 __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned char* __restrict__ x,
@@ -1797,7 +1800,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 #pragma unroll
             for (int m = 0; m < 4; ++m)
               if (m < 3 || lane < 32)
-                *reinterpret_cast<u32x4*>(dst0 + g * (2 * 56 * 128) + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
+                store16_out<HIPAC_NT_STEM != 0>(dst0 + g * (2 * 56 * 128) + s_off[m], *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16));
             if constexpr (Q8) {
               unsigned char* const qdst0 = out_q + ((((size_t)b * 56 + 4 * ys) * 56 + 28 * side + 14 * st) * 128 + jt * 32) + g * (2 * 56 * 128);
 #pragma unroll
@@ -1894,7 +1897,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_strip2_kernel(const unsigned
 #pragma unroll
           for (int m = 0; m < 4; ++m)
             if (m < 3 || lane < 32)
-              *reinterpret_cast<u32x4*>(dst0 + s_off[m]) = *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16);
+              store16_out<HIPAC_NT_STEM != 0>(dst0 + s_off[m], *reinterpret_cast<const u32x4*>(Sl + (lane + 64 * m) * 16));
           }
         }
         HALO_STAMP(z_te);

@@ -777,8 +777,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
             const int sch = 4 * jp + 2 * (g & 1) + (g >> 1);  // the 16-byte chunk of the wave's 128 bytes this lane holds
             *reinterpret_cast<u32x4*>(Sw16 + spx * 128 + ((sch ^ (spx & 7)) << 4)) = u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
           } else if ((HIPAC_H16_ABL & 32) ? m < 0 : m < M)  // (ablation 32: no stores)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + c_lane + 32 * jp) =
-                u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
+            store16_out<HIPAC_NT_STORES && (H * W >= 784)>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + c_lane + 32 * jp, u32x4{P[0][0], P[0][1], P[1][0], P[1][1]});
         }
         if constexpr (STAGE16 && (i & 1)) {
           // the 32-pixel group is staged: out as whole 128-byte lines -- 8 lanes per pixel, 16 bytes each

@@ -648,8 +648,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
           permlane16_swap(PL[2 * jp][1], PL[2 * jp + 1][1]);
         }
         if ((HIPAC_Q8_ABL & 16) ? m < 0 : m < M) {
-          *reinterpret_cast<u32x4*>(out_h + 32 * jp) = u32x4{PH[2 * jp][0], PH[2 * jp][1], PH[2 * jp + 1][0], PH[2 * jp + 1][1]};
-          if constexpr (LO16) *reinterpret_cast<u32x4*>(out_h + COUT + 32 * jp) = u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]};
+          store16_out<false>(out_h + 32 * jp, u32x4{PH[2 * jp][0], PH[2 * jp][1], PH[2 * jp + 1][0], PH[2 * jp + 1][1]});
+          if constexpr (LO16) store16_out<false>(out_h + COUT + 32 * jp, u32x4{PL[2 * jp][0], PL[2 * jp][1], PL[2 * jp + 1][0], PL[2 * jp + 1][1]});
         }
       }
       if constexpr (Q8OUT) {
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         // the wave's 64 channels are one chunk of the q8 tensor: row [lo8: 64 | hi8: 64]
         unsigned char* const qrow = out_q + (size_t)m * (2 * COUT) + ((n0 + wn * WTN) >> 6) * 128 + 32 * (g >> 1) + 16 * (g & 1);
         if ((HIPAC_Q8_ABL & 16) ? m < 0 : m < M) {
-          *reinterpret_cast<u32x4*>(qrow) = u32x4{QL[0], QL[1], QL[2], QL[3]};
-          *reinterpret_cast<u32x4*>(qrow + 64) = u32x4{QH[0], QH[1], QH[2], QH[3]};
+          store16_out<false>(qrow, u32x4{QL[0], QL[1], QL[2], QL[3]});
+          store16_out<false>(qrow + 64, u32x4{QH[0], QH[1], QH[2], QH[3]});
         }
       }
     }
