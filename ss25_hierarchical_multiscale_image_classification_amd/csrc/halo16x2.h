@@ -37,6 +37,9 @@
                             // requested after the stores could only be waited for by draining every one of them (each stays counted until
                             // its data is in L2).  0: NSW - 1 tiles ahead, the first in-loop request at step 0 (halo16.h's schedule)
 #endif
+#ifndef HIPAC_Q8_RESID_AHEAD
+#define HIPAC_Q8_RESID_AHEAD 2  // residual fragments in flight in the identity-MFMA pass (6 measured equal: 136.0 vs 136.2 k patches/s)
+#endif
 #ifndef HIPAC_Q8_NSW64
 #define HIPAC_Q8_NSW64 4  // weight ring slots of the BN = 64 (layer1) form: 2 .. 4
 #endif
@@ -501,14 +504,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         __builtin_amdgcn_s_barrier();
       }
       const unsigned rb = BOTH && part ? rb0 + (unsigned)(Wbuf - Abuf) : rb0;
-      frag rf[4];
-      static_for<2>([&](auto S) { lds_read16<(decltype(S)::value >> 1) * 2048>(rf[decltype(S)::value], (decltype(S)::value & 1) ? rb ^ 64u : rb); });
+      // fragments (i, kk) in the order (0,0) (0,1) (1,0) ...: RA of them in flight (the K loop's fragment registers are free now)
+      constexpr int RA = HIPAC_Q8_RESID_AHEAD;
+      static_assert(RA >= 2 && RA <= 8 && RA <= 2 * MT, "residual read-ahead");
+      frag rf[RA];
+      static_for<RA>([&](auto S) { lds_read16<(decltype(S)::value >> 1) * 2048>(rf[decltype(S)::value], (decltype(S)::value & 1) ? rb ^ 64u : rb); });
       static_for<2 * MT>([&](auto S) {
         constexpr int s2 = decltype(S)::value, i = s2 >> 1, kk = s2 & 1;
-        if constexpr (s2 + 2 < 2 * MT) lds_read16<((s2 + 2) >> 1) * 2048>(rf[(s2 + 2) & 3], ((s2 + 2) & 1) ? rb ^ 64u : rb);
-        wait_lgkmcnt<(s2 + 2 < 2 * MT) ? 2 : (2 * MT - 1 - s2)>();
-        Asm16<T>::mfma(acc[i][2 * kk], ident[0], rf[s2 & 3]);
-        Asm16<T>::mfma(acc[i][2 * kk + 1], ident[1], rf[s2 & 3]);
+        // (the slot of fragment s2 - 1 is free: its two MFMAs were issued in the previous sub-step)
+        if constexpr (s2 >= 1 && s2 - 1 + RA < 2 * MT) lds_read16<((s2 - 1 + RA) >> 1) * 2048>(rf[(s2 - 1 + RA) % RA], ((s2 - 1 + RA) & 1) ? rb ^ 64u : rb);
+        constexpr int issued = (s2 == 0 ? RA : (s2 - 1 + RA < 2 * MT ? s2 + RA : 2 * MT));  // fragments requested so far
+        wait_lgkmcnt<issued - s2 - 1>();
+        Asm16<T>::mfma(acc[i][2 * kk], ident[0], rf[s2 % RA]);
+        Asm16<T>::mfma(acc[i][2 * kk + 1], ident[1], rf[s2 % RA]);
       });
     }
   }
