@@ -59,7 +59,10 @@ Plan make_plan(int batch, int precision) {
   // needs thousands of images (default group 4096) to fill 256 CUs x 2 workgroups for several rounds.
   // (tuning knobs; a whole run must use one setting)
   const int bc_cap = env_int("HIPAC_SUBBATCH", 512, 1, 1024);
-  const int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
+  int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
+  // fp16q8: halo16x2.h addresses its pair tensors with 32-bit byte offsets (buffer descriptors): layer3's stride-2 entry conv sees
+  // 4 x gc x 196 pixels x 128 channels x 4 bytes, which stays below 2^31 up to gc = 5 349
+  if (precision == HIPAC_PREC_FP16Q8 && gc_cap > 4096) gc_cap = 4096;
   p.fuse_stem = wide_mode(precision) ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
