@@ -443,8 +443,8 @@ def run_resnet(args, rank, world, dev):
                                     "tflops_network_arithmetic": vx3 * FLOP_PER_PATCH / 1e12,
                                     "tflops_mfma_issued": 3 * vx3 * FLOP_PER_PATCH / 1e12,
                                     "frac_of_f16_mfma_peak": 3 * vx3 * FLOP_PER_PATCH / 1e12 / PEAK_BF16_DENSE_TFLOPS,
-                                    "note": "every product = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2 products in the stem: "
-                                            "bytes are exact); meets_1e-3 is measured in `parity`"}
+                                    "note": "every product = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (halo16x2.h, X3 form; 2 products in the "
+                                            "stem: bytes are exact); meets_1e-3 is measured in `parity`"}
         # the debugging reference: fp32 storage, exact f32 MFMA
         net32 = capi.PackedResNet18(sd, precision="fp32")
         n32 = min(B, 2048)

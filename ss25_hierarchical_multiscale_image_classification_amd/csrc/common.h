@@ -179,7 +179,7 @@ int launch_head(const float* last, int n, const float* fc_w, const float* fc_b, 
                 float* feats, float* logits, int64_t* labels, hipStream_t s);
 int launch_head_pool(const float* part, int n, const float* fc_w, const float* fc_b, int num_classes,
                      float* feats, float* logits, int64_t* labels, hipStream_t s);
-bool q8_entry_convs();  // conv_f16q8.hip: do fp16q8's stride-2 entry convs take halo16x2.h's weight rows (HIPAC_Q8_S2)?
+bool x3_on_halo16();  // conv_f16x3.hip: does fp16x3 run on halo16x2.h (weight rows [whi | wlo] per chunk) or on the round-3 SPLIT kernels?
 bool halo_pool_compiled();  // conv_bf16.hip: was the 16x16x32 halo kernel with the direct epilogue compiled in?
 int launch_tap_export(const void* src, int is_f32, int precision, int n, int C, int H, int W, float* dst,
                       hipStream_t s);

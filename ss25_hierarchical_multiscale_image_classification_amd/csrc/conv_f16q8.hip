@@ -4,7 +4,6 @@
 namespace hipac {
 int run_trunk_f16q8(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                     hipStream_t s, int first, int last) {
-  return run_trunk<_Float16, true, true>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
+  return run_trunk<_Float16, true, 1>(net, p, ws, xin, n_early, img_off, n_late, s, first, last);
 }
-bool q8_entry_convs() { return HIPAC_Q8_S2 != 0; }
 }  // namespace hipac

@@ -2975,15 +2975,17 @@ struct Q8Map {
   size_t q8;
   void* of(const void* pairs) const { return ws + q8 + (size_t)((const char*)pairs - ws) / 2; }
 };
-#ifndef HIPAC_Q8_S2
-#define HIPAC_Q8_S2 1  // fp16q8: the stride-2 entry convs on halo16x2.h's stride-2 form (0: the fp16x3 kernels + pairs_to_q8_kernel)
+#ifndef HIPAC_X3_HALO16
+#define HIPAC_X3_HALO16 1  // fp16x3: every 3x3 conv on halo16x2.h's X3 form (16x16x32 MFMA, parity-plane entry convs, folded projection, pooled head);
+                           // 0: round 3's SPLIT forms of the 32x32x16 kernels
 #endif
-template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0, bool LO16 = true>  // HW: the OUTPUT map
+template <int CIN, int COUT, int HW, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0, bool LO16 = true,
+          bool X3 = false>  // HW: the OUTPUT map
 static int launch_halo16x2(const void* in, const void* in_q, const ConvW& w, const void* resid, void* out, void* out_q, int n, hipStream_t s,
                            const void* resid_q = nullptr, const void* wgt_p = nullptr, const float* bias = nullptr) {
   constexpr int BM = 256, BN = COUT % 128 == 0 ? 128 : 64;
   constexpr int LDS = halo_band_pieces(HW, BM) * 1024 + (BN == 64 ? HIPAC_Q8_NSW64 : 2) * BN * 128;
-  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32, S2, PCIN, LO16>;
+  auto kern = conv3x3_halo16x2_kernel<CIN, COUT, HW, HW, BN, RELU, RESID, Q8OUT, POOL, OUTF32, S2, PCIN, LO16, X3>;
   static bool attr_done[kMaxDevices] = {};
   if (int rc_attr = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_attr;
   const int M = n * HW * HW;
@@ -2994,6 +2996,16 @@ static int launch_halo16x2(const void* in, const void* in_q, const ConvW& w, con
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const _Float16*)in, (const unsigned char*)in_q, (const unsigned char*)w.w, bias ? bias : w.bias,
                      (const _Float16*)resid, out, (unsigned char*)out_q, M, n, n_mtiles, (const unsigned char*)resid_q, (const unsigned char*)wgt_p);
   return (int)hipGetLastError();
+}
+// the two pair modes' convs through one call: MODE 1 = fp16q8 (byte tensors, flags as given), MODE 2 = fp16x3 on the same kernel (pairs
+// only: no q8 output, the lo plane always written)
+template <int MODE, int CIN, int COUT, int HW, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0, bool LO16 = true>
+static int launch_pairconv(const void* in, const void* in_q, const ConvW& w, const void* resid, void* out, void* out_q, int n, hipStream_t s,
+                           const void* resid_q = nullptr, const void* wgt_p = nullptr, const float* bias = nullptr) {
+  if constexpr (MODE == 2)
+    return launch_halo16x2<CIN, COUT, HW, true, RESID, false, POOL, OUTF32, S2, PCIN, true, true>(in, nullptr, w, resid, out, nullptr, n, s, nullptr, wgt_p, bias);
+  else
+    return launch_halo16x2<CIN, COUT, HW, true, RESID, Q8OUT, POOL, OUTF32, S2, PCIN, LO16, false>(in, in_q, w, resid, out, out_q, n, s, resid_q, wgt_p, bias);
 }
 
 // The trunk is a fixed sequence of 21 launches ("ops"): 0 stem, 1 max-pool, then per
@@ -3009,65 +3021,36 @@ struct OpRange {
 
 // One ResNet stage = two BasicBlocks.  CI/HI: input channels / spatial size,
 // CO/HO: output.  STRIDE 2 stages carry the 1x1/2 projection shortcut.
-template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false, bool Q8 = false>
+template <typename T, int CI, int CO, int HI, int STRIDE, bool LAST, bool SPLIT = false, int PM = 0>
 static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* ds, void* o0, void* o1, int n,
                      hipStream_t s, OpRange& ops, bool fuse_blocks = false, void* pool_part = nullptr, Q8Map qm = Q8Map{nullptr, 0}) {
   constexpr int HO = HI / STRIDE;
   const ConvW(&bw)[2] = net.block[2 * stage];
   const ConvW(&bw1)[2] = net.block[2 * stage + 1];
   const char* z = net.zero_page;
-  if constexpr (Q8) {
-    // precision fp16q8: the stride-1 convs on halo16x2.h (pair + q8 tensors); the stage's entry conv and projection are the
-    // fp16x3 kernels, whose pair output gets its q8 tensor from pairs_to_q8_kernel (the same op slot)
-    static_assert(SPLIT && sizeof(T) == 2, "fp16q8 extends the pair layout");
-    const void* idt = x;
-    const void* c2_in = tmp;
+  if constexpr (PM != 0) {
+    // the pair modes on halo16x2.h -- PM 1: precision fp16q8 (pair + q8 tensors), PM 2: fp16x3 (pairs only, three f16 products).
+    // Stride-2 stages: the entry conv on the parity-plane form, the 1x1 / stride 2 projection shortcut folded into the block's second
+    // conv as extra K steps (its op slot is empty).  A block's first conv leaves the lo plane out in fp16q8 (nothing reads it).
+    static_assert(SPLIT && sizeof(T) == 2, "the pair layout");
+    auto Q = [&](const void* pairs) -> void* { return PM == 1 ? qm.of(pairs) : nullptr; };
     if constexpr (STRIDE == 1) {
-      if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, false, 0, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
+      if (ops.take()) HIPAC_TRY((launch_pairconv<PM, CI, CO, HO, false, true, false, false, false, 0, false>(x, Q(x), bw[0], nullptr, tmp, Q(tmp), n, s)));
+      if (ops.take()) HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, true, true, false>(tmp, Q(tmp), bw[1], x, o0, Q(o0), n, s)));
     } else {
-      if constexpr (HIPAC_Q8_S2) {
-        // the entry conv on the stride-2 form (reads the q8 tensor the previous stage's last conv wrote); the 1x1 / stride 2
-        // projection shortcut rides in the block's second conv as extra K steps (its op slot is empty)
-        if (ops.take()) HIPAC_TRY((launch_halo16x2<CI, CO, HO, true, false, true, false, false, true, 0, false>(x, qm.of(x), bw[0], nullptr, tmp, qm.of(tmp), n, s)));
-        (void)ops.take();
-        if (ops.take())
-          HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, CI>(c2_in, qm.of(c2_in), bw[1], x, o0, qm.of(o0), n, s, qm.of(x),
-                                                                                              net.down[stage - 1].w, net.bias_c2p[stage - 1])));
-        if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, 0, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
-        if (ops.take()) {
-          if constexpr (LAST) {
-            if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
-            else HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false, true>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
-          } else {
-            HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, true, false>(tmp, qm.of(tmp), bw1[1], o0, o1, qm.of(o1), n, s)));
-          }
-        }
-        return 0;
-      } else if constexpr (HIPAC_FUSE_PROJ && CO <= HIPAC_FUSE_PROJ_MAXCO) {
-        if (ops.take()) {
-          HIPAC_TRY((launch_down<T, CI, CO, HI, true>(x, bw[0], net.down[stage - 1], tmp, ds, n, s, z)));
-          HIPAC_TRY(launch_pairs_to_q8(tmp, qm.of(tmp), (long long)n * HO * HO, CO, s));
-        }
-        (void)ops.take();
-      } else {
-        if (ops.take()) {
-          HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 3, STRIDE, true, false, false, false, true>(x, bw[0], nullptr, tmp, n, s, z)));
-          HIPAC_TRY(launch_pairs_to_q8(tmp, qm.of(tmp), (long long)n * HO * HO, CO, s));
-        }
-        if (ops.take())
-          HIPAC_TRY((launch_conv<T, CI, CO, HI, HI, 1, STRIDE, false, false, false, false, true>(x, net.down[stage - 1], nullptr, ds, n, s, z)));
-      }
-      idt = ds;
+      if (ops.take()) HIPAC_TRY((launch_pairconv<PM, CI, CO, HO, false, true, false, false, true, 0, false>(x, Q(x), bw[0], nullptr, tmp, Q(tmp), n, s)));
+      (void)ops.take();
+      if (ops.take())
+        HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, false, true, false, false, false, CI>(tmp, Q(tmp), bw[1], x, o0, Q(o0), n, s, Q(x), net.down[stage - 1].w,
+                                                                                          net.bias_c2p[stage - 1])));
     }
-    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, true, false>(c2_in, qm.of(c2_in), bw[1], idt, o0, qm.of(o0), n, s)));
-    if (ops.take()) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, false, true, false, false, false, 0, false>(o0, qm.of(o0), bw1[0], nullptr, tmp, qm.of(tmp), n, s)));
+    if (ops.take()) HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, false, true, false, false, false, 0, false>(o0, Q(o0), bw1[0], nullptr, tmp, Q(tmp), n, s)));
     if (ops.take()) {
       if constexpr (LAST) {
-        if (pool_part) HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, true>(tmp, qm.of(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
-        else HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, false, false, true>(tmp, qm.of(tmp), bw1[1], o0, o1, nullptr, n, s)));
+        if (pool_part) HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, true, false, true>(tmp, Q(tmp), bw1[1], o0, pool_part, nullptr, n, s)));
+        else HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, true, false, false, true>(tmp, Q(tmp), bw1[1], o0, o1, nullptr, n, s)));
       } else {
-        // (HIPAC_Q8_S2: the next stage's entry conv reads this output's q8 tensor)
-        HIPAC_TRY((launch_halo16x2<CO, CO, HO, true, true, HIPAC_Q8_S2 != 0, false>(tmp, qm.of(tmp), bw1[1], o0, o1, HIPAC_Q8_S2 ? qm.of(o1) : nullptr, n, s)));
+        HIPAC_TRY((launch_pairconv<PM, CO, CO, HO, true, true, false>(tmp, Q(tmp), bw1[1], o0, o1, Q(o1), n, s)));  // (its q8 tensor feeds the next stage's entry conv)
       }
     }
     return 0;
@@ -3140,7 +3123,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   return 0;
 }
 
-template <typename T, bool SPLIT = false, bool Q8 = false>
+template <typename T, bool SPLIT = false, int PM = 0>  // PM: pair mode (run_stage)
 static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, int n_early, int img_off, int n_late,
                      hipStream_t s, int first, int last) {
   OpRange ops{first, last, 0};
@@ -3154,9 +3137,9 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
         const int n_strips = 2 * ne;
         const int n_pairs = (n_strips + 1) / 2;
         const int sgrid = n_pairs < 256 ? n_pairs : 256;
-        hipLaunchKernelGGL((stem_pool_strip2_kernel<T, true, Q8>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
+        hipLaunchKernelGGL((stem_pool_strip2_kernel<T, true, PM == 1>), dim3(sgrid), dim3(512), 0, s, (const unsigned char*)xin,
                            (const T*)net.stem_u8.w, net.stem_u8.bias, (T*)(ws + p.pool), n_strips,
-                           ne * kPatch * kPatch * 3, Q8 ? (unsigned char*)qm.of(ws + p.pool) : nullptr);
+                           ne * kPatch * kPatch * 3, PM == 1 ? (unsigned char*)qm.of(ws + p.pool) : nullptr);
         HIPAC_TRY((int)hipGetLastError());
       }
       (void)ops.take();
@@ -3169,7 +3152,7 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
       hipLaunchKernelGGL((maxpool3x3s2_split_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                          (const float*)(ws + p.stem), (_Float16*)(ws + p.pool), ne);
       HIPAC_TRY((int)hipGetLastError());
-      if constexpr (Q8) HIPAC_TRY(launch_pairs_to_q8(ws + p.pool, qm.of(ws + p.pool), (long long)ne * 56 * 56, 64, s));
+      if constexpr (PM == 1) HIPAC_TRY(launch_pairs_to_q8(ws + p.pool, qm.of(ws + p.pool), (long long)ne * 56 * 56, 64, s));
     }
     }
     fused_done = true;
@@ -3212,14 +3195,14 @@ static int run_trunk(const Net& net, const Plan& p, char* ws, const void* xin, i
     }
   // layer2's second block writes straight into this sub-batch's slice of the group buffer
   char* l2out = ws + p.blk[3] + (size_t)img_off * 28 * 28 * 128 * p.esz;
-  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false, SPLIT, Q8>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
+  HIPAC_TRY((run_stage<T, 64, 64, 56, 1, false, SPLIT, PM>(net, 0, ws + p.pool, ws + p.tmp_e, nullptr, ws + p.blk[0], ws + p.blk[1], ne, s, ops,
                                                            p.l1_fused != 0, nullptr, qm)));
-  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT, Q8>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops, false,
+  HIPAC_TRY((run_stage<T, 64, 128, 56, 2, false, SPLIT, PM>(net, 1, ws + p.blk[1], ws + p.tmp_e, ws + p.ds_e, ws + p.blk[2], l2out, ne, s, ops, false,
                                                             nullptr, qm)));
-  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT, Q8>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops,
+  HIPAC_TRY((run_stage<T, 128, 256, 28, 2, false, SPLIT, PM>(net, 2, ws + p.blk[3], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[4], ws + p.blk[5], nl, s, ops,
                                                              false, nullptr, qm)));
-  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT, Q8>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops,
-                                                            false, p.pool_head && (Q8 || halo_pool_available<T, SPLIT>()) ? ws + p.part : nullptr, qm)));
+  HIPAC_TRY((run_stage<T, 256, 512, 14, 2, true, SPLIT, PM>(net, 3, ws + p.blk[5], ws + p.tmp_l, ws + p.ds_l, ws + p.blk[6], ws + p.blk[7], nl, s, ops,
+                                                            false, p.pool_head && (PM != 0 || halo_pool_available<T, SPLIT>()) ? ws + p.part : nullptr, qm)));
   return 0;
 }
 

@@ -106,8 +106,11 @@ static int launch_pairs_to_q8(const void* in, void* q, long long n_pix, int C, h
 // [COUT][PCIN / 64][hi16: 64 | whi8: 64 | wlo8: 64]); `bias` = the conv's + the projection's.
 // LO16: write the lo plane of the output pairs.  Only a later residual add reads it (the next conv takes the hi plane and the q8
 // tensor), so a block's FIRST conv leaves it out: a third of its output bytes and stores.
+// X3 (precision fp16x3 on this kernel): no byte tensors -- the second band of a chunk is the LO plane of the pair tensor and all three
+// products run on the f16 MFMA: per chunk the hi band x the tiles [whi | wlo] of each tap (two steps per tap on the same activation
+// addresses), then the lo band x whi: 27 steps.  Weight rows [Cout][tap][C / 64][whi: 64 f16 | wlo: 64 f16] (the q8 rows' size).
 template <int CIN, int COUT, int H, int W, int BN, bool RELU, bool RESID, bool Q8OUT, bool POOL, bool OUTF32 = false, bool S2 = false, int PCIN = 0,
-          bool LO16 = true>
+          bool LO16 = true, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16* __restrict__ in, const unsigned char* __restrict__ in_q,
                                                                   const unsigned char* __restrict__ wgt, const float* __restrict__ bias,
                                                                   const _Float16* __restrict__ resid, void* __restrict__ outp,
@@ -132,7 +135,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   constexpr int WPW = BN / 8 / 4;
   constexpr int NTILES_N = COUT / BN;
   constexpr int PCC = PCIN / 64;                    // chunks of the folded projection (0: none)
-  constexpr int NSTEP = 9 * VC + 2 * PCC;
+  constexpr int SPC = X3 ? 27 : 18;                 // K steps per chunk
+  constexpr int SPP = X3 ? 3 : 2;                   // ... per chunk of the projection
+  constexpr int NSTEP = CC * SPC + SPP * PCC;
+  static_assert(!X3 || (!Q8OUT && LO16), "fp16x3: pairs in, pairs out");
   constexpr int PRE = HIPAC_Q8_PRE_ALL ? NSW : NSW - 1;  // weight tiles requested ahead of a tile's first step
   static_assert(NSTEP > NSW, "K steps");
   constexpr int S_BYTES = NSW * W_BYTES;
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   auto issue_plane_band = [&](int k, int v) {
     if constexpr (S2) {
       const int py = k < 4 ? 1 : (k < 6 ? 0 : (k < 8 ? 1 : 0)), px = k < 6 ? 1 : 0;
-      if (v & 1) {
+      if (!X3 && (v & 1)) {
         const int pofs = (py * 2 * W + px) * (CIN * 2) + (v >> 1) * 128 + swz16;
 #pragma unroll
         for (int kk = 0; kk < NPB; ++kk) {
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         asm volatile("" ::: "memory");
         return;
       }
-      const int pofs = (py * 2 * W + px) * (CIN * 4) + (v >> 1) * 128 + swz16;
+      const int pofs = (py * 2 * W + px) * (CIN * 4) + (v >> 1) * 128 + swz16 + (X3 && (v & 1) ? CIN * 2 : 0);
 #pragma unroll
       for (int kk = 0; kk < NPB; ++kk) {
         const int p = wave + 4 * kk;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     }
     const int mlast_ = (m0_ + BM <= M ? m0_ + BM : M) - 1;
     const int npieces_ = (mlast_ - m0_ + 1 + 2 * W + 2 + 2 + 7) >> 3;
-    if (v & 1) {
+    if (!X3 && (v & 1)) {
       const int base = (m0_ - W - 3) * (CIN * 2) + (v >> 1) * 128;
       for (int p = wave; p < npieces_; p += 4) {
         int off = q_lane + base + p * (8 * CIN * 2);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       asm volatile("" ::: "memory");  // (keeps hipcc from merging the two paths into one with a SELECTED descriptor: halo16.h, issue_w)
       return;
     }
-    const int base = (m0_ - W - 3) * (CIN * 4) + (v >> 1) * 128;
+    const int base = (m0_ - W - 3) * (CIN * 4) + (v >> 1) * 128 + (X3 && (v & 1) ? CIN * 2 : 0);  // (X3, odd v: the lo plane)
     for (int p = wave; p < npieces_; p += 4) {
       int off = h_lane + base + p * (8 * CIN * 4);
       if (p == 0 && prow < 2) off = (int)0x80000000;
@@ -261,8 +267,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   const rsrc_t w_rsrc = make_rsrc(wgt, COUT * KROW);
   const rsrc_t wp_rsrc = make_rsrc(PCC > 0 ? wgt_p : wgt, COUT * (PCC > 0 ? PCC * 256 : KROW));
   auto issue_w = [&](int step, int slot_) {  // step = 9 v + tap: bytes [tap][v][128] of the row
-    if (PCC > 0 && step >= 9 * VC) {  // uniform: a projection step, row bytes [pc][kind][128]
-      const int kofs_p = (step - 9 * VC) * 128;
+    if (PCC > 0 && step >= CC * SPC) {  // uniform: a projection step, row bytes [pc][256]: (hi, whi) (X3: (hi, wlo)) then the second band's tile
+      const int idx = step - CC * SPC;
+      const int kofs_p = X3 ? (idx / 3) * 256 + (idx % 3 == 1 ? 128 : 0) : idx * 128;
       static_for<WPW>([&](auto I) {
         constexpr int i = decltype(I)::value;
         buffer_load_lds16(wp_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, wp_off[PCC > 0 ? i : 0], kofs_p);
@@ -270,8 +277,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
       asm volatile("" ::: "memory");  // (see issue_band_of)
       return;
     }
-    const int v = step / 9, tap = step - v * 9;
-    const int kofs_bytes = (S2 ? b16_tap<2>(tap) : tap) * (VC * 128) + v * 128;  // (S2: `tap` is the position in plane order)
+    // step = c SPC + j.  q8: j < 9 the hi band's taps (row bytes [0, 128) of the chunk), then the q8 band's ([128, 256)).
+    // X3: j < 18 the hi band's (tap, tile) pairs -- tile 0 = whi ([0, 128)), 1 = wlo ([128, 256)) --, then the lo band's taps x whi
+    const int c = step / SPC, j = step - c * SPC;
+    const int tap = X3 ? (j < 18 ? j >> 1 : j - 18) : (j < 9 ? j : j - 9);
+    const int sel = X3 ? (j < 18 ? j & 1 : 0) : (j < 9 ? 0 : 1);
+    const int kofs_bytes = (S2 ? b16_tap<2>(tap) : tap) * (VC * 128) + c * 256 + sel * 128;  // (S2: `tap` is the position in plane order)
     static_for<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       buffer_load_lds16(w_rsrc, Wbuf + slot_ * W_BYTES + (wave + 4 * i) * 1024, w_off[i], kofs_bytes);
@@ -382,34 +393,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   }
   for (int c = 0; c < CC; ++c) {
     static_for<2>([&](auto KIND) {
-      constexpr int kind = decltype(KIND)::value;  // 0: hi band x f16 weights, 1: q8 band x fp8 weights
+      constexpr int kind = decltype(KIND)::value;  // 0: hi band x f16 weights, 1: q8 band x fp8 weights (X3: lo band x f16 weights)
+      constexpr int TPT = (X3 && kind == 0) ? 2 : 1;  // weight tiles per tap (X3, hi band: whi then wlo on the same addresses)
+      constexpr bool F8 = kind == 1 && !X3;
       if (c > 0 || kind > 0) {
         __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
         issue_band_of(m0, 2 * c + kind);
       }
 #pragma unroll HIPAC_HALO_TAP_UNROLL
-      for (int tap = 0; tap < 9; ++tap, ++s) {
-        if (S2 && (tap == 4 || tap == 6 || tap == 8)) {  // the next plane's band (its round trip is exposed: the wait below drains it)
+      for (int tap = 0; tap < 9; ++tap) {
+        const bool plane_switch = S2 && (tap == 4 || tap == 6 || tap == 8);
+        if (plane_switch) {  // the next plane's band (its round trip is exposed: the wait below drains it)
           __builtin_amdgcn_s_barrier();
           issue_plane_band(tap, 2 * c + kind);
         }
-        // W(s) must have landed -- W(s + 1 .. s + NSW - 2) were requested after it and may stay in flight; the band too at tap 0 and
-        // behind a plane switch (it was requested after them all: drain)
-        if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
-        else if (tap != 0 && !(S2 && (tap == 4 || tap == 6 || tap == 8))) {
-          if (HIPAC_Q8_PRE_ALL && s < NSW) {
-            // W(s) was requested ahead of the tile and step 0's wait covered it
-          } else if (NSW > 2 && s + NSW - 2 < NSTEP) wait_vmcnt<(NSW - 2) * WPW>();
-          else wait_vmcnt<0>();
-        } else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
         const int tap_w = S2 ? b16_tap<2>(tap) : tap;  // the tap's index in the weights
         const int kh = tap_w / 3, kw = tap_w - kh * 3;
         const int toff = S2 ? (kh == 0 ? -W : 0) + (kw == 0 ? -1 : 0) : (kh - 1) * W + kw - 1;
-        const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
         const unsigned tapmask = ((kw == 0 ? 1u : 0u) | (!S2 && kw == 2 ? 2u : 0u) | (kh == 0 ? 4u : 0u) | (!S2 && kh == 2 ? 8u : 0u)) * 0x11111111u;
         const int qt = q0 + toff;
-        const int x0 = (kind ? g << 5 : g << 4) ^ (((qt >> 1) & 7) << 4);
+        const int x0 = (F8 ? g << 5 : g << 4) ^ (((qt >> 1) & 7) << 4);
         const int a_in = (qt << 7) + x0;
         const int a_zero = ((qt & 1) << 7) + x0;
         unsigned em;
@@ -417,18 +420,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
         int a_addr[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_addr[i] = (em & (0xFu << (4 * i))) ? a_zero : a_in + 2048 * i;
-        auto mid = [&] {
-          // the slot of step s - 1 was freed by this step's barrier (PRE_ALL: at step 0 there is no such slot, every one was filled ahead)
-          if (s + NSW - 1 < NSTEP && (!HIPAC_Q8_PRE_ALL || s > 0)) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
-        };
-        if constexpr (kind) {
-          if constexpr (HIPAC_Q8_ABL & 4) mid();
-          else k_step8(wst, a_addr, mid);
-        } else {
-          if constexpr (HIPAC_Q8_ABL & 8) mid();
-          else k_step(wst, a_addr, mid);
+#pragma unroll
+        for (int t = 0; t < TPT; ++t, ++s) {
+          // W(s) must have landed -- W(s + 1 .. s + NSW - 2) were requested after it and may stay in flight; the band too at its
+          // first step and behind a plane switch (it was requested after them all: drain)
+          if (s == 0 && prev_full) wait_vmcnt<N_EPI_STORES>();  // the prefetch is older than the previous epilogue's stores
+          else if (!(t == 0 && (tap == 0 || plane_switch))) {
+            if (HIPAC_Q8_PRE_ALL && s < NSW) {
+              // W(s) was requested ahead of the tile and step 0's wait covered it
+            } else if (NSW > 2 && s + NSW - 2 < NSTEP) wait_vmcnt<(NSW - 2) * WPW>();
+            else wait_vmcnt<0>();
+          } else wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+          auto mid = [&] {
+            // the slot of step s - 1 was freed by this step's barrier (PRE_ALL: at step 0 there is no such slot, every one was filled ahead)
+            if (s + NSW - 1 < NSTEP && (!HIPAC_Q8_PRE_ALL || s > 0)) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+          };
+          if constexpr (F8) {
+            if constexpr (HIPAC_Q8_ABL & 4) mid();
+            else k_step8(wst, a_addr, mid);
+          } else {
+            if constexpr (HIPAC_Q8_ABL & 8) mid();
+            else k_step(wst, a_addr, mid);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     });
   }
@@ -443,6 +460,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
     for (int pc = 0; pc < PCC; ++pc) {
       static_for<2>([&](auto KIND) {
         constexpr int kind = decltype(KIND)::value;
+        constexpr int TPT = (X3 && kind == 0) ? 2 : 1;
+        constexpr bool F8 = kind == 1 && !X3;
         __builtin_amdgcn_s_barrier();  // every wave has finished reading the previous band
         for (int p = wave + (first >> 3); p <= (last >> 3); p += 4) {
           const int q = p * 8 + prow;
@@ -451,23 +470,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
           const int b = mm / (H * W), rem = mm - b * (H * W), y = rem / W, x = rem - y * W;
           const int pix = (b * (2 * H) + 2 * y) * (2 * W) + 2 * x;
           const int schunk = (dchunk ^ ((q >> 1) & 7)) * 16;
-          if constexpr (kind) buffer_load_lds16(pq_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 2) + pc * 128 + schunk : (int)0x80000000, 0);
-          else buffer_load_lds16(ph_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 4) + pc * 128 + schunk : (int)0x80000000, 0);
+          if constexpr (F8) buffer_load_lds16(pq_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 2) + pc * 128 + schunk : (int)0x80000000, 0);
+          else buffer_load_lds16(ph_rsrc, Abuf + p * 1024, ok ? pix * (PCIN * 4) + pc * 128 + schunk + (kind ? PCIN * 2 : 0) : (int)0x80000000, 0);
         }
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
-        const int a_in = (q0 << 7) + ((kind ? g << 5 : g << 4) ^ (((q0 >> 1) & 7) << 4));
+        const int a_in = (q0 << 7) + ((F8 ? g << 5 : g << 4) ^ (((q0 >> 1) & 7) << 4));
         int a_addr[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_addr[i] = a_in + 2048 * i;
-        auto mid = [&] {
-          if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
-        };
-        if constexpr (kind) k_step8(wst, a_addr, mid);
-        else k_step(wst, a_addr, mid);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ++s;
+#pragma unroll
+        for (int t = 0; t < TPT; ++t, ++s) {
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          const unsigned char* wst = Wbuf + (s % NSW) * W_BYTES;
+          auto mid = [&] {
+            if (s + NSW - 1 < NSTEP) issue_w(s + NSW - 1, (s + NSW - 1) % NSW);
+          };
+          if constexpr (F8) k_step8(wst, a_addr, mid);
+          else k_step(wst, a_addr, mid);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
       });
     }
   }

@@ -62,12 +62,13 @@ Plan make_plan(int batch, int precision) {
   int gc_cap = env_int("HIPAC_GROUP", 4096, 1, 8192);
   // fp16q8: halo16x2.h addresses its pair tensors with 32-bit byte offsets (buffer descriptors): layer3's stride-2 entry conv sees
   // 4 x gc x 196 pixels x 128 channels x 4 bytes, which stays below 2^31 up to gc = 5 349
-  if (precision == HIPAC_PREC_FP16Q8 && gc_cap > 4096) gc_cap = 4096;
+  if ((precision == HIPAC_PREC_FP16Q8 || (precision == HIPAC_PREC_FP16X3 && x3_on_halo16())) && gc_cap > 4096) gc_cap = 4096;
   p.fuse_stem = wide_mode(precision) ? 0 : env_int("HIPAC_FUSE_STEM", 1, 0, 1);
   p.u8_input = 0;
   p.stem_strip = env_int("HIPAC_STEM_STRIP", 1, 0, 1);
   p.l1_fused = wide_mode(precision) ? 0 : env_int("HIPAC_L1_FUSED", 1, 0, 1);
-  p.pool_head = ((wide_mode(precision) && precision != HIPAC_PREC_FP16Q8) || !halo_pool_compiled()) ? 0 : env_int("HIPAC_POOL_HEAD", 1, 0, 1);
+  const bool on_halo16x2 = precision == HIPAC_PREC_FP16Q8 || (precision == HIPAC_PREC_FP16X3 && x3_on_halo16());
+  p.pool_head = ((wide_mode(precision) && !on_halo16x2) || !halo_pool_compiled()) ? 0 : env_int("HIPAC_POOL_HEAD", 1, 0, 1);
   if (batch < 1) batch = 1;
   p.bc = batch < bc_cap ? batch : bc_cap;
   p.gc = batch < gc_cap ? batch : gc_cap;
@@ -381,7 +382,8 @@ static int pack_conv_split3(const hipac_convbn_t& c, int cout, int cin, float ep
 
 // fp16q8, 3x3 / stride 1 convs (halo16x2.h): BN folded, every weight split into the fp16 pair (hi, lo); per output channel and tap,
 // per 64-channel chunk 256 bytes: [hi: 64 fp16 | e4m3(hi * 2^4): 64 | e4m3(lo * 2^15): 64]
-static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out, int taps) {
+// (q8 = false: fp16x3 on the same kernel -- the second 128 bytes of a chunk are the 64 lo halves as fp16)
+static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out, int taps, bool q8 = true) {
   HIPAC_REQUIRE(c.conv_w && c.bn_gamma && c.bn_beta && c.bn_mean && c.bn_var, HIPAC_EINVAL,
                 "pack: null tensor pointer (cout=%d cin=%d q8)", cout, cin);
   HIPAC_REQUIRE(cin % 64 == 0, HIPAC_EINVAL, "pack: q8 layout needs cin %% 64 == 0 (%d)", cin);
@@ -402,8 +404,12 @@ static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, C
         memcpy(&ll, &lb, 2);
         uint8_t* row = &w[(size_t)o * KROW + ((size_t)tap * (cin / 64) + i / 64) * 256];
         memcpy(row + (i % 64) * 2, &hb, 2);
-        row[128 + (i % 64)] = f32_to_e4m3(ldexpf((float)hh, 4));
-        row[192 + (i % 64)] = f32_to_e4m3(ldexpf((float)ll, 15));
+        if (q8) {
+          row[128 + (i % 64)] = f32_to_e4m3(ldexpf((float)hh, 4));
+          row[192 + (i % 64)] = f32_to_e4m3(ldexpf((float)ll, 15));
+        } else {
+          memcpy(row + 128 + (i % 64) * 2, &lb, 2);
+        }
       }
   }
   int rc = upload(w.data(), w.size(), &out->w);
@@ -412,6 +418,7 @@ static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, C
 }
 
 static int pack_conv_q8_3x3(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) { return pack_conv_q8(c, cout, cin, eps, out, 9); }
+static int pack_conv_x3rows_3x3(const hipac_convbn_t& c, int cout, int cin, float eps, ConvW* out) { return pack_conv_q8(c, cout, cin, eps, out, 9, false); }
 
 // Stem weights for the strip kernel (uint8 input, conv_igemm.h: stem_pool_strip_kernel): BN folded as in
 // pack_conv, ToTensor / Normalize (reference src/main.py:815-816) folded too -- the kernel feeds the centred byte
@@ -594,14 +601,15 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
   const int ch[4] = {64, 128, 256, 512};
   for (int s = 0; s < 4 && !rc && split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
-    auto pack3 = q8 ? pack_conv_q8_3x3 : pack_conv_split3;
-    rc = (s == 0 || q8_entry_convs() ? pack3 : pack_conv_split3)(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
+    const bool rows = q8 || x3_on_halo16();  // halo16x2.h's weight rows
+    auto pack3 = q8 ? pack_conv_q8_3x3 : rows ? pack_conv_x3rows_3x3 : pack_conv_split3;
+    rc = pack3(params->block[2 * s][0], ch[s], cin, eps, &w->net.block[2 * s][0]);
     if (!rc) rc = pack3(params->block[2 * s][1], ch[s], ch[s], eps, &w->net.block[2 * s][1]);
     if (!rc) rc = pack3(params->block[2 * s + 1][0], ch[s], ch[s], eps, &w->net.block[2 * s + 1][0]);
     if (!rc) rc = pack3(params->block[2 * s + 1][1], ch[s], ch[s], eps, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0)
-      rc = q8 && q8_entry_convs() ? pack_conv_q8(params->down[s - 1], ch[s], cin, eps, &w->net.down[s - 1], 1)  // (folded into conv2: halo16x2.h, PCIN)
-                                  : pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
+      rc = rows ? pack_conv_q8(params->down[s - 1], ch[s], cin, eps, &w->net.down[s - 1], 1, q8)  // (folded into conv2: halo16x2.h, PCIN)
+                : pack_conv_split(params->down[s - 1], ch[s], cin, 1, eps, &w->net.down[s - 1]);
   }
   for (int s = 0; s < 4 && !rc && !split; ++s) {
     const int cin = s == 0 ? 64 : ch[s - 1];
@@ -611,7 +619,7 @@ int hipac_resnet18_pack(const hipac_resnet18_params_t* params, int precision, hi
     if (!rc) rc = pack_conv(params->block[2 * s + 1][1], ch[s], ch[s], 3, eps, precision, false, &w->net.block[2 * s + 1][1]);
     if (!rc && s > 0) rc = pack_conv(params->down[s - 1], ch[s], cin, 1, eps, precision, false, &w->net.down[s - 1]);
   }
-  for (int st = 1; st < 4 && !rc && (!wide_mode(precision) || q8); ++st) {
+  for (int st = 1; st < 4 && !rc && (!wide_mode(precision) || q8 || (split && x3_on_halo16())); ++st) {
     // block0.conv2's bias + the projection's, for the kernel that accumulates both into one accumulator
     const hipac_convbn_t& a = params->block[2 * st][1];
     const hipac_convbn_t& b = params->down[st - 1];
@@ -831,7 +839,9 @@ int hipac_resnet18_tap(const hipac_weights_t* w, const void* workspace, int batc
       // (same accumulators) on the activations still in the workspace
       Plan q = p;
       q.pool_head = 0;
-      auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16 : w->net.precision == HIPAC_PREC_FP16Q8 ? run_trunk_f16q8 : run_trunk_f16;
+      auto trunk = w->net.precision == HIPAC_PREC_BF16 ? run_trunk_bf16
+                   : w->net.precision == HIPAC_PREC_FP16Q8 ? run_trunk_f16q8
+                   : w->net.precision == HIPAC_PREC_FP16X3 ? run_trunk_f16x3 : run_trunk_f16;
       int rc_t = trunk(w->net, q, (char*)workspace, nullptr, 0, 0, batch, (hipStream_t)stream, kNumOps - 1, kNumOps - 1);
       HIPAC_REQUIRE(rc_t == 0, rc_t, "tap: re-running the last conv failed (%d)", rc_t);
     }
