@@ -3054,7 +3054,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
       }
     }
     return 0;
-  }
+  } else {  // (the single-value precisions, and HIPAC_X3_HALO16=0: round 3's SPLIT kernels)
   // second conv of the stage's second block; for the network's last one (LAST) either the fp32 map or, with `pool_part`,
   // the per-image partial sums of the global average pool (halo16.h, POOL)
   auto launch_last = [&](const void* in_, const void* resid_, void* out_) -> int {
@@ -3121,6 +3121,7 @@ static int run_stage(const Net& net, int stage, const void* x, void* tmp, void* 
   if (ops.take()) HIPAC_TRY((launch_conv<T, CO, CO, HO, HO, 3, 1, true, false, false, false, SPLIT>(o0, bw1[0], nullptr, tmp, n, s, z)));
   if (ops.take()) HIPAC_TRY((launch_last(tmp, o0, o1)));
   return 0;
+  }
 }
 
 template <typename T, bool SPLIT = false, int PM = 0>  // PM: pair mode (run_stage)
