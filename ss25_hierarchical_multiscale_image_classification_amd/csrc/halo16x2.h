@@ -40,6 +40,9 @@
 #ifndef HIPAC_Q8_RESID_AHEAD
 #define HIPAC_Q8_RESID_AHEAD 2  // residual fragments in flight in the identity-MFMA pass (6 measured equal: 136.0 vs 136.2 k patches/s)
 #endif
+#ifndef HIPAC_Q8_AH8
+#define HIPAC_Q8_AH8 2  // activation fragments (two ds_read_b128 each) in flight ahead of the fp8 sub-step being issued
+#endif
 #ifndef HIPAC_Q8_NSW64
 #define HIPAC_Q8_NSW64 4  // weight ring slots of the BN = 64 (layer1) form: 2 .. 4
 #endif
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   // the two halves of an 8-register operand.  Reads in issue order: W[0..NT) (2 each), A[0..AH), then A[s + AH] in sub-step s;
   // LDS returns in order, so sub-step s waits until only the 2 min(AH, MT - 1 - s) reads issued after A[s] are outstanding
   auto k_step8 = [&](const unsigned char* wst, const int (&a_addr)[MT], auto&& mid) {
-    constexpr int AH = S2 ? 1 : 2;  // (S2: the per-lane plane offsets need the registers; a sub-step is 128 cycles of MFMA)
+    constexpr int AH = S2 ? 1 : HIPAC_Q8_AH8;  // (S2: the per-lane plane offsets need the registers; a sub-step is 128 cycles of MFMA)
     u32x4 wl[NT], wh[NT], al[AH + 1], ah[AH + 1];
     const unsigned w0 = lds0 + (unsigned)(wst - ring) + (unsigned)rdw8;
     const unsigned w1 = w0 ^ 16u;
