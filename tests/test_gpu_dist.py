@@ -22,7 +22,7 @@ def _run_ranks(helper, args, n=2, timeout=900):
     assert [p.wait(timeout=timeout) for p in procs] == [0] * n
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["fp16q8", "fp16x3", "bf16"])
 def test_two_rank_sharded_slides_equal_single_process(tmp_path, precision):
     """configs[3] in miniature: 3 synthetic slides, slide i -> rank i mod 2 (`dist.shard_units`), `extract.score_slide`
     per slide, `dist.gather_results`.  The rank-major result is the single-process result of slides (0, 2, 1) bit for
