@@ -99,6 +99,11 @@ void set_error(const char* fmt, ...);
     }                                    \
   } while (0)
 
+// precision fp16q8 (halo16x2.h): the constant power-of-two scales of the e4m3 byte planes.  Activations: hi8 = e4m3(hi), lo8 = e4m3(lo * 2^11);
+// weights (pack_conv_q8): whi8 = e4m3(whi * 2^4), wlo8 = e4m3(wlo * 2^15).  Both cross products carry 2^(11 + 4) = 2^(0 + 15).
+constexpr int kQ8LoShift = 11, kQ8WhiShift = 4, kQ8WloShift = 15;
+static_assert(kQ8LoShift + kQ8WhiShift == kQ8WloShift, "one scale for both cross products");
+
 // ---- packed network description shared by the TUs ---------------------------------
 struct ConvW {
   void* w;      // device, T[Cout][K] (K = kh*kw*Cin, or 7*32 for the stem)

@@ -67,9 +67,8 @@ __device__ __forceinline__ unsigned cvt4_e4m3(float a, float b, float c, float d
 #else
 __device__ inline unsigned cvt4_e4m3(float, float, float, float) { return 0; }
 #endif
-constexpr float kQ8LoScale = 2048.f;  // activations' lo parts are converted as lo * 2^11
-constexpr int kQ8WhiShift = 4, kQ8WloShift = 15;  // weights: whi * 2^4, wlo * 2^15 (pack_conv_q8); 11 + 4 = 0 + 15
-constexpr int kQ8ScaleA = 127 - 15, kQ8ScaleB = 127;  // E8M0 scale operands of the MFMA
+constexpr float kQ8LoScale = (float)(1 << kQ8LoShift);  // activations' lo parts are converted as lo * 2^11 (common.h has the shifts)
+constexpr int kQ8ScaleA = 127 - kQ8WloShift, kQ8ScaleB = 127;  // E8M0 scale operands of the MFMA: 2^-15 on the weight side
 
 // pair tensor -> q8 tensor, for the activations the mode's other kernels produce (stem + pool, the stride-2 entry convs)
 template <int UNUSED = 0>  // (a template: the header is part of several translation units)

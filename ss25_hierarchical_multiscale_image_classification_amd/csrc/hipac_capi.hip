@@ -405,8 +405,8 @@ static int pack_conv_q8(const hipac_convbn_t& c, int cout, int cin, float eps, C
         uint8_t* row = &w[(size_t)o * KROW + ((size_t)tap * (cin / 64) + i / 64) * 256];
         memcpy(row + (i % 64) * 2, &hb, 2);
         if (q8) {
-          row[128 + (i % 64)] = f32_to_e4m3(ldexpf((float)hh, 4));
-          row[192 + (i % 64)] = f32_to_e4m3(ldexpf((float)ll, 15));
+          row[128 + (i % 64)] = f32_to_e4m3(ldexpf((float)hh, kQ8WhiShift));
+          row[192 + (i % 64)] = f32_to_e4m3(ldexpf((float)ll, kQ8WloShift));
         } else {
           memcpy(row + 128 + (i % 64) * 2, &lb, 2);
         }
