@@ -74,11 +74,15 @@ def conv3(x, w, b, fmt, mode, **kw):
     return (y + b.double()[None, :, None, None]).float()
 
 
-def sim(x, sd, fmt, mode):
+def sim(x, sd, fmt, mode, stem_single=False):
     sd = R.canonical_state_dict(sd)
     w, b = fold(sd, 'conv1', 'bn1')
-    # the stem keeps the fp16x3 kernel's arithmetic (bytes exact, weights as pairs: two exact products)
-    y = F.relu(conv3(x, w, b, None, 'x3' if mode == 'x3' else 'x1', stride=2, padding=3))
+    if stem_single:
+        # the stem as ONE product: input exact (bytes), weights rounded to fp16 (no lo halves)
+        y = F.relu((F.conv2d(x.double(), pair(w)[0].double(), None, stride=2, padding=3) + b.double()[None, :, None, None]).float())
+    else:
+        # the stem keeps the fp16x3 kernel's arithmetic (bytes exact, weights as pairs: two exact products)
+        y = F.relu(conv3(x, w, b, None, 'x3' if mode == 'x3' else 'x1', stride=2, padding=3))
     y = F.max_pool2d(y, 3, 2, 1)
     for name, _, stride in R.STAGES:
         for blk in (0, 1):
@@ -108,4 +112,7 @@ with torch.no_grad():
                           ('fp16x3 (exact cross terms)', None, 'x3'), ('cross terms MXFP8 e4m3', 'e4m3', 'x3'),
                           ('cross terms MXFP6 e2m3', 'e2m3', 'x3'), ('single fp16 product', None, 'x1')]:
         f, l = sim(x, sd, fmt, mode)
+        if fmt == 'e4m3const':
+            f1, l1 = sim(x, sd, fmt, mode, stem_single=True)
+            print(f"{'... with a one-product stem':30s} feats {rel(f1, rf):.2e} logits {rel(l1, rl):.2e} labels equal {bool((l1.argmax(1) == rl.argmax(1)).all())}", flush=True)
         print(f'{nm:30s} feats {rel(f, rf):.2e} logits {rel(l, rl):.2e} labels equal {bool((l.argmax(1) == rl.argmax(1)).all())}', flush=True)
