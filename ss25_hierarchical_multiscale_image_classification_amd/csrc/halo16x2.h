@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16x2_kernel(const _Float16
   }
   const rsrc_t w_rsrc = make_rsrc(wgt, COUT * KROW);
   const rsrc_t wp_rsrc = make_rsrc(PCC > 0 ? wgt_p : wgt, COUT * (PCC > 0 ? PCC * 256 : KROW));
-  auto issue_w = [&](int step, int slot_) {  // step = 9 v + tap: bytes [tap][v][128] of the row
+  auto issue_w = [&](int step, int slot_) {  // the 128-byte-per-channel weight tile of K step `step` (decoded below) into ring slot `slot_`
     if (PCC > 0 && step >= CC * SPC) {  // uniform: a projection step, row bytes [pc][256]: (hi, whi) (X3: (hi, wlo)) then the second band's tile
       const int idx = step - CC * SPC;
       const int kofs_p = X3 ? (idx / 3) * 256 + (idx % 3 == 1 ? 128 : 0) : idx * 128;
