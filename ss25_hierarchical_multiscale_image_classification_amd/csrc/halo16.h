@@ -114,7 +114,7 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
                                 // entry convs -2..-3 %, the rest +-0), 0: round-robin
 #endif
 #ifndef HIPAC_H16_ABL
-#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects, 32 no stores
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects, 32 no stores, 64 (stride-2 form) no band reload at the plane switches
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
     }
 #pragma unroll HIPAC_HALO_TAP_UNROLL
     for (int tap = 0; tap < 9; ++tap, ++s) {
-      if (S2 && (tap == 4 || tap == 6 || tap == 8)) {  // the next plane's band (its round trip is exposed: the wait below drains it)
+      if (S2 && !(HIPAC_H16_ABL & 64) && (tap == 4 || tap == 6 || tap == 8)) {  // the next plane's band (its round trip is exposed: the wait below drains it)
         __builtin_amdgcn_s_barrier();
         issue_plane_band(tap, cc);
       }
