@@ -26,10 +26,22 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
                            // loop that never reads its output cannot show.  Left off.
 #endif
 // 16-byte activation store of a conv epilogue
+#ifndef HIPAC_WT_STORES
+#define HIPAC_WT_STORES 0  // developer experiment: 1 = `sc1` (write-through: the line goes to memory at once and stays valid in the L2), 2 = `sc0 sc1`, 3 = `nt sc1`.
+                           // Whole forward, alternating runs on one box: 312.9 k plain, 312.1 / 312.0 / 313.0 k -- no policy moves it
+#endif
 template <bool NT>
 __device__ __forceinline__ void store16_out(void* p, u32x4 v) {
+#if HIPAC_WT_STORES == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif HIPAC_WT_STORES == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif HIPAC_WT_STORES == 3
+  asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+#else
   if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
   else *reinterpret_cast<u32x4*>(p) = v;
+#endif
 }
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(8))) short s16x8;

@@ -114,7 +114,7 @@ __host__ __device__ constexpr int perm16_inv(int j) { return (j & 1) ? (j + 7) /
                                 // entry convs -2..-3 %, the rest +-0), 0: round-robin
 #endif
 #ifndef HIPAC_H16_ABL
-#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects, 32 no stores, 64 (stride-2 form) no band reload at the plane switches
+#define HIPAC_H16_ABL 0  // developer builds (wrong results): 1 no per-step barrier, 2 no weight DMA in the K loop, 4 no fragment waits, 8 no wait for the weight DMA, 16 no image-edge selects, 32 no stores, 64 (stride-2 form) no band reload at the plane switches, 128 stores wrapped into a 16 K-pixel window (the instructions without the HBM write traffic)
 #endif
 #ifndef HIPAC_H16_SB
 #define HIPAC_H16_SB 1
@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo16_kernel(const T* __restr
             const int sch = 4 * jp + 2 * (g & 1) + (g >> 1);  // the 16-byte chunk of the wave's 128 bytes this lane holds
             *reinterpret_cast<u32x4*>(Sw16 + spx * 128 + ((sch ^ (spx & 7)) << 4)) = u32x4{P[0][0], P[0][1], P[1][0], P[1][1]};
           } else if ((HIPAC_H16_ABL & 32) ? m < 0 : m < M)  // (ablation 32: no stores)
-            store16_out<HIPAC_NT_STORES && (H * W >= 784)>(reinterpret_cast<T*>(outp) + (size_t)m * COUT + c_lane + 32 * jp, u32x4{P[0][0], P[0][1], P[1][0], P[1][1]});
+            store16_out<HIPAC_NT_STORES && (H * W >= 784)>(reinterpret_cast<T*>(outp) + (size_t)((HIPAC_H16_ABL & 128) ? (m & 0x3fff) : m) * COUT + c_lane + 32 * jp,
+                                                           u32x4{P[0][0], P[0][1], P[1][0], P[1][1]});  // (ablation 128: every store into one L2-resident window)
         }
         if constexpr (STAGE16 && (i & 1)) {
           // the 32-pixel group is staged: out as whole 128-byte lines -- 8 lanes per pixel, 16 bytes each
